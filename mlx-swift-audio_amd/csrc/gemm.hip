@@ -1,0 +1,227 @@
+// gemm.hip -- dense "NT" contraction on the gfx950 matrix cores: C[M,N] = epi(A[M,K] . W[N,K]^T).
+//
+// This is the only place the encoder's true dense contractions run:
+// Linear layers (MLXNN Linear: y = x W^T + b, weight [out,in]) and the two Conv1d layers of
+// AudioEncoder.swift:47-48, which are expressed as GEMMs over *overlapping* row windows of the channels-last
+// input (row stride = conv stride * Cin, K = 3 * Cin) -- no im2col buffer exists.
+//
+// Structure (CDNA4, wave64): 128x128x64 tile, 256 threads = 2x2 waves, each wave 64x64 as 4x4
+// v_mfma_f32_16x16x32 tiles with fp32 accumulation.  Operands are staged HBM -> registers -> LDS
+// (issue-early / write-late, one barrier per K-step, double-buffered LDS), rows of 128 B with the 16-B chunk
+// index XOR-swizzled by (row & 7) so every ds_read_b128 of a fragment is bank-conflict free.  The MFMA is
+// issued with W as the "A" operand, so each lane's 4 accumulator registers run along N (contiguous in C):
+// the epilogue emits 8-byte (16-bit C) or 16-byte (fp32 C) stores.
+// Workgroup ids are remapped so that the blocks sharing an XCD (and its private L2) walk neighbouring tiles.
+#include "gemm.h"
+#include "mia_device.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB per operand tile
+
+template <typename T>
+__device__ __forceinline__ float apply_act(float v, int act) {
+  return act == MIA_ACT_GELU ? gelu_erf(v) : v;
+}
+
+template <typename T, bool OUT_F32, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [2 buffers][A|W]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // ---- XCD-aware tile mapping (bijective form; MI355X deals consecutive block ids round-robin to 8 XCDs)
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int bz = blockIdx.z;
+
+  const uint16_t* __restrict__ A = reinterpret_cast<const uint16_t*>(g.A) + (int64_t)bz * g.strideA;
+  const uint16_t* __restrict__ W = reinterpret_cast<const uint16_t*>(g.W);
+
+  // ---- staging: each thread moves 4 x 16 B of A and 4 x 16 B of W per K-step
+  const int s_row = tid >> 3;          // 0..31 (+32*i)
+  const int s_chk = tid & 7;           // 16-B chunk within the 128-B row
+  const uint16_t* a_src[4];
+  const uint16_t* w_src[4];
+  int s_dst[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = s_row + 32 * i;
+    int am = m0 + row; am = am < g.M ? am : g.M - 1;      // clamp: tail rows are computed but never stored
+    int wn = n0 + row; wn = wn < g.N ? wn : g.N - 1;
+    a_src[i] = A + (int64_t)am * g.lda + s_chk * 8;
+    w_src[i] = W + (int64_t)wn * g.K + s_chk * 8;
+    s_dst[i] = row * 128 + ((s_chk ^ (row & 7)) << 4);
+  }
+  u32x4 ra[4], rw[4];
+  auto load_regs = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + k0);
+      rw[i] = *reinterpret_cast<const u32x4*>(w_src[i] + k0);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    char* base = lds + buf * 2 * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(base + s_dst[i]) = ra[i];
+      *reinterpret_cast<u32x4*>(base + TILE_BYTES + s_dst[i]) = rw[i];
+    }
+  };
+
+  // ---- fragment read addresses (row = base + lane&15, chunk = kk*4 + lane>>4)
+  const int f_row = lane & 15, f_chk = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  load_regs(0);
+  write_lds(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_regs((kt + 1) * BK);
+    const char* sa = lds + cur * 2 * TILE_BYTES;
+    const char* sw = sa + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      s16x8 fa[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ar = wr * 64 + t * 16 + f_row;
+        fa[t] = *reinterpret_cast<const s16x8*>(sa + ar * 128 + (((kk * 4 + f_chk) ^ (ar & 7)) << 4));
+        const int wrow = wc * 64 + t * 16 + f_row;
+        fw[t] = *reinterpret_cast<const s16x8*>(sw + wrow * 128 + (((kk * 4 + f_chk) ^ (wrow & 7)) << 4));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = T::mfma16(fw[nt], fa[mt], acc[mt][nt]);  // rows<-n, cols<-m
+    }
+    if (kt + 1 < nk) write_lds(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds, per (mt,nt), C[m = ..+lane&15][n = ..+(lane>>4)*4 + 0..3]
+  const int e_m = lane & 15, e_n = (lane >> 4) * 4;
+  const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && (g.R == nullptr || (g.ldr & 3) == 0);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wr * 64 + mt * 16 + e_m;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wc * 64 + nt * 16 + e_n;
+      if (n >= g.N) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j];
+      if (g.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += g.bias[n + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(v[j], g.act);
+      if (g.R) {
+        const float* r = g.R + (int64_t)bz * g.strideR + (int64_t)m * g.ldr + n;
+        if (vec_ok) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(r);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += rv[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += r[j];
+        }
+      }
+      if (EPI == MIA_EPI_STD) {
+        if (OUT_F32) {
+          float* c = reinterpret_cast<float*>(g.C) + (int64_t)bz * g.strideC + (int64_t)m * g.ldc + n;
+          if (vec_ok) *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n + j < g.N) c[j] = v[j];
+          }
+        } else {
+          uint16_t* c = reinterpret_cast<uint16_t*>(g.C) + (int64_t)bz * g.strideC + (int64_t)m * g.ldc + n;
+          if (vec_ok) *reinterpret_cast<u32x2*>(c) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n + j < g.N) c[j] = T::from_f32(v[j]);
+          }
+        }
+      } else if (EPI == MIA_EPI_QKV_VT) {
+        // columns [0, 2D): q|k rows, row stride ldc.  columns [2D, 3D): V, stored transposed per head:
+        // vt[((b*H + h)*64 + d) * Tpad + t]   (m = b*T + t, n - 2D = h*64 + d)
+        const int D2 = 2 * g.H * 64;
+        if (n < D2) {
+          uint16_t* c = reinterpret_cast<uint16_t*>(g.C) + (int64_t)m * g.ldc + n;
+          *reinterpret_cast<u32x2*>(c) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+        } else {
+          const int b = m / g.T, t = m - b * g.T;
+          const int hd = n - D2;   // h*64 + d
+          uint16_t* vt = reinterpret_cast<uint16_t*>(g.C2) + ((int64_t)b * g.H * 64 + hd) * g.Tpad + t;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vt[(int64_t)j * g.Tpad] = T::from_f32(v[j]);
+        }
+      } else {  // MIA_EPI_HEADMAJOR: out[((b*H + h)*T + t)*64 + d], n = h*64 + d (4 consecutive n share a head)
+        const int b = m / g.T, t = m - b * g.T;
+        const int h = n >> 6, d = n & 63;
+        uint16_t* c = reinterpret_cast<uint16_t*>(g.C) + (((int64_t)b * g.H + h) * g.T + t) * 64 + d;
+        *reinterpret_cast<u32x2*>(c) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_t(const GemmArgs& g, hipStream_t s) {
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  dim3 grid(tiles, 1, g.batch > 0 ? g.batch : 1), block(256);
+  if (g.epi == MIA_EPI_STD) {
+    if (g.out_f32) hipLaunchKernelGGL((gemm_nt_kernel<T, true, MIA_EPI_STD>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, false, MIA_EPI_STD>), grid, block, 0, s, g);
+  } else if (g.epi == MIA_EPI_QKV_VT) {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, false, MIA_EPI_QKV_VT>), grid, block, 0, s, g);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, false, MIA_EPI_HEADMAJOR>), grid, block, 0, s, g);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+const char* mia_gemm_check(const GemmArgs& g) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return "gemm: M, N, K must be > 0";
+  if (g.K % BK != 0) return "gemm: K must be a multiple of 64";
+  if (g.lda % 8 != 0) return "gemm: lda must be a multiple of 8 elements (16-byte rows)";
+  if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return "gemm: A and W must be 16-byte aligned";
+  if (g.strideA % 8 != 0) return "gemm: strideA must be a multiple of 8 elements";
+  if (g.epi != MIA_EPI_STD) {
+    if (g.out_f32) return "gemm: special epilogues emit 16-bit output only";
+    if (g.T <= 0 || g.H <= 0) return "gemm: special epilogue needs T and H";
+    if (g.batch > 1) return "gemm: special epilogues use the flattened M = B*T form";
+    if (g.epi == MIA_EPI_QKV_VT && (g.N != 3 * g.H * 64 || g.ldc % 4 != 0 || g.Tpad < g.T || !g.C2)) return "gemm: bad QKV_VT arguments";
+    if (g.epi == MIA_EPI_HEADMAJOR && g.N != g.H * 64) return "gemm: HEADMAJOR needs N == H*64";
+  }
+  return nullptr;
+}
+
+int mia_gemm_launch(const GemmArgs& g, int dtype, hipStream_t s) {
+  return dtype == MIA_F16 ? launch_t<F16>(g, s) : launch_t<BF16>(g, s);
+}

@@ -1,0 +1,82 @@
+// mia_device.h -- device-side helpers shared by the gfx950 kernels (wave64, MFMA fragments, 16-bit types).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define MIA_WAVE 64
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;      // 8 x 16-bit payload (bf16 MFMA operand)
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;   // 8 x f16 (f16 MFMA operand)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---- 16-bit storage types: bf16 (tag 2) and f16 (tag 1) share every kernel via this trait --------
+struct BF16 {
+  static constexpr int tag = 2;
+  static __device__ __forceinline__ float to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    __hip_bfloat16 b = __float2bfloat16(f);  // RNE, NaN preserving (v_cvt_pk_bf16_f32)
+    return *reinterpret_cast<uint16_t*>(&b);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+  }
+};
+
+struct F16 {
+  static constexpr int tag = 1;
+  static __device__ __forceinline__ float to_f32(uint16_t v) {
+    _Float16 h = __builtin_bit_cast(_Float16, v);
+    return (float)h;
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    _Float16 h = (_Float16)f;  // RNE
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
+}
+
+// ---- wave64 reductions ----------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU, MLXNN GELU() default
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// order-preserving float <-> int key (for atomicMax on floats of either sign)
+__device__ __forceinline__ int float_to_ordered(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ordered_to_float(int k) {
+  int i = k >= 0 ? k : k ^ 0x7fffffff;
+  return __int_as_float(i);
+}

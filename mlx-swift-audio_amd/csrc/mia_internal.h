@@ -1,0 +1,62 @@
+// mia_internal.h -- shared host-side plumbing for the HIP layer (context, workspace, error handling).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mia.h"
+
+struct mia_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // grow-only scratch arena in HBM (never freed between calls: no hipMalloc on the hot path)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  // cached per-n_mels front-end tables (device)
+  struct MelTables {
+    int n_mels = 0;
+    int window_kind = -1;
+    float* window = nullptr;    // [400]
+    float* twiddle = nullptr;   // [400][2][224] cos|sin
+    float* fb_w = nullptr;      // compact non-zero filter weights
+    int* fb_meta = nullptr;     // [n_mels][3] = (first bin, count, offset into fb_w)
+    int fb_nnz = 0;
+  };
+  std::vector<MelTables> mel_tables;
+};
+
+inline int mia_fail(mia_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define MIA_HIP(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return mia_fail((ctx), MIA_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                      __FILE__, __LINE__);                                                      \
+  } while (0)
+
+#define MIA_CHECK_ARG(ctx, cond, ...)                                   \
+  do {                                                                  \
+    if (!(cond)) return mia_fail((ctx), MIA_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
+  } while (0)
+
+// Ensure the ctx workspace holds at least `bytes`; returns nullptr on failure (ctx->err set).
+void* mia_workspace(mia_ctx* ctx, size_t bytes);
+
+inline size_t mia_dtype_size(int dt) { return dt == MIA_F32 ? 4 : 2; }
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
