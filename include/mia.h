@@ -78,6 +78,83 @@ int mia_logmel_whisper(mia_ctx* ctx, const float* pcm, const int64_t* offs, int 
 int mia_logmel_s3(mia_ctx* ctx, const float* pcm, const int64_t* offs, int B, int n_mels,
                   int64_t pad_right, int64_t n_frames_out, void* mel, int out_dtype, int mem);
 
+/* ---- Whisper ---------------------------------------------------------------------------------- */
+/* Model dimensions == ModelDimensions (STT/Whisper/Config/WhisperConfig.swift:9-86), read by the caller
+ * from config.json. */
+typedef struct {
+  int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} mia_whisper_dims;
+
+/* A named host tensor handed to the loader (safetensors entry, already mapped by the caller).
+ * Names follow the reference's Module key schema (@ModuleInfo keys in STT/Whisper/Layers/ *.swift), e.g.
+ *   encoder.conv1.weight [Cout,3,Cin]   encoder.blocks.0.attn.query.weight [D,D]
+ *   decoder.token_embedding.weight [V,D]  decoder.positional_embedding [n_text_ctx,D]  decoder.ln.weight [D]
+ * `encoder.positional_embedding` is optional (sinusoids, AudioEncoder.swift:78-96, are computed when absent). */
+typedef struct {
+  const char* name;
+  int32_t dtype;      /* mia_dtype of `data` */
+  int32_t ndim;
+  int64_t shape[4];
+  const void* data;   /* host pointer, C-contiguous */
+} mia_tensor_view;
+
+/* Decoding options == DecodingOptions + the integer tables the reference's tokenizer provides
+ * (STT/Whisper/WhisperDecoding.swift:14-51,104-122,190-206; STT/Whisper/WhisperTokenizer.swift:72-96,489-532).
+ * The tokenizer itself (a CPU text codec) stays on the caller's side; its outputs arrive as arrays. */
+typedef struct {
+  const int32_t* initial_tokens; /* [n_initial] shared by all clips, or [B][n_initial] if per_clip_initial:
+                                    ([sot_prev]+prompt)? + sotSequence (+ no_timestamps when timestamps off) */
+  int32_t n_initial;
+  int32_t per_clip_initial;
+  int32_t sot_index;             /* index of <|startoftranscript|> inside initial_tokens (no-speech probe) */
+  const int32_t* suppress_ids;   /* nonSpeechTokens + {transcribe, translate, sot, sot_prev, sot_lm, no_speech} */
+  int32_t n_suppress;
+  const int32_t* blank_ids;      /* tokenizer.encode(" "): suppressed together with eot on the first step only */
+  int32_t n_blank;
+  int32_t eot, no_speech, no_timestamps, timestamp_begin;
+  int32_t timestamps;            /* 0 = TimestampGranularity.none, 1 = segment/word rules active */
+  int32_t max_tokens;            /* DecodingOptions.maxTokens (448): budget = max_tokens - n_initial */
+  int32_t max_initial_timestamp_index; /* 50 (WhisperDecoding.swift:281) */
+  int32_t max_new_tokens;        /* extra cap on generated tokens per clip (0 = none); benchmarking aid */
+  float temperature;             /* 0 = greedy (argmax).  > 0: inverse-CDF sampling with caller-provided uniforms */
+  const float* uniforms;         /* [B][max_tokens] in [0,1) when temperature > 0 (explicit RNG), else NULL */
+} mia_decode_opts;
+
+/* Replaces WhisperModel.load's tensor upload (STT/Whisper/WhisperModel.swift:184-206).  compute_dtype is MIA_BF16
+ * or MIA_F16 (storage type of weights/activations; accumulation and the residual stream are fp32). */
+mia_whisper* mia_whisper_load(mia_ctx* ctx, const mia_whisper_dims* dims, const mia_tensor_view* tensors, int n_tensors,
+                              int compute_dtype);
+void mia_whisper_free(mia_whisper* w);
+
+/* Replaces model.encode(mel) (WhisperDecoding.swift:98 -> AudioEncoder.swift:43-68) for a batch of 30 s windows and
+ * primes the decoder's cross-attention K/V (MultiHeadAttention.swift:49-59).
+ *   mel: [B][2*n_audio_ctx][n_mels] in the model's compute dtype. */
+int mia_whisper_encode(mia_whisper* w, const void* mel, int B, int mem);
+/* Copy the audio features of the last encode ([B][n_audio_ctx][n_audio_state]) out as `dtype` (test hook). */
+int mia_whisper_get_audio_features(mia_whisper* w, void* out, int dtype, int mem);
+
+/* Replaces GreedyDecoder.decode's loop (WhisperDecoding.swift:135-359) for the B clips of the last encode:
+ * decoder forward with KV cache, logit rules, argmax / sampling, log-prob bookkeeping; all on device.
+ *   tokens        int32 [B][max_tokens]: generated tokens (EOT stripped), zero padded
+ *   n_tokens      int32 [B]
+ *   avg_logprob   float [B]   sum logp / count(non-EOT)            (WhisperDecoding.swift:345-362)
+ *   no_speech_prob float [B]  softmax(logits[sot_index])[no_speech] (WhisperDecoding.swift:158-169)
+ * Output pointers are host or device according to `mem`. */
+int mia_whisper_decode_greedy(mia_whisper* w, const mia_decode_opts* opts, int32_t* tokens, int32_t* n_tokens,
+                              float* avg_logprob, float* no_speech_prob, int mem);
+
+/* Language detection (WhisperModel.swift:223-260): one decoder step on [sot]; argmax/softmax over the language
+ * token range [sot+1, sot+1+n_languages).  lang_idx int32 [B], prob float [B] (host pointers). */
+int mia_whisper_detect_language(mia_whisper* w, int32_t sot, int32_t n_languages, int32_t* lang_idx, float* prob);
+
+/* One 30 s window per clip, end to end (log-mel -> encode -> greedy decode), i.e. the body of the reference's
+ * transcribe loop for a batch (WhisperSTT.swift:140-145,181-213).  pcm/offs as in mia_logmel_whisper; pcm and the
+ * outputs live in `mem`. */
+int mia_whisper_transcribe_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right,
+                                   const mia_decode_opts* opts, int32_t* tokens, int32_t* n_tokens, float* avg_logprob,
+                                   float* no_speech_prob, int mem);
+
 #ifdef __cplusplus
 }
 #endif

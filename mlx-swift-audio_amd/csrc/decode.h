@@ -1,0 +1,23 @@
+// decode.h -- internal interface between whisper_decode.hip (host loop) and decode_kernels.hip.
+#pragma once
+#include "whisper.h"
+
+enum { SK_OUT16 = 0, SK_OUTF32 = 1, SK_PARTIAL = 2, SK_QKV = 3 };
+
+struct SkinnyArgs {
+  const uint16_t* A; int64_t lda;        // [M][K]
+  const uint16_t* W;                     // [N][K]
+  const float* bias;
+  void* out; int64_t ldo;                // OUT16 / OUTF32: [M][ldo];  PARTIAL: [S][M][N];  QKV: q [M][D]
+  uint16_t* cache_k; uint16_t* cache_v;  // QKV: [B][H][n_ctx][64] of this layer
+  const DecState* st;
+  int M, N, K, S, act, D, H, n_ctx;
+};
+
+int dec_launch_embed_ln(mia_whisper* w, const LNW& ln, hipStream_t s);
+int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln, hipStream_t s);
+int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s);
+int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const void* vc, void* out, int fixed_keys, int cap_keys,
+                         hipStream_t s);
+int dec_launch_head(mia_whisper* w, int32_t* last_ts, const DecodeParams& p, hipStream_t s);
+int dec_launch_finalize(mia_whisper* w, int32_t* out_n, const DecodeParams& p, hipStream_t s);

@@ -1,0 +1,211 @@
+// whisper_encode.hip -- batched Whisper encoder forward + cross-attention K/V priming on gfx950.
+// Replaces AudioEncoder.callAsFunction (STT/Whisper/Layers/AudioEncoder.swift:43-68), the encoder half of
+// ResidualAttentionBlock (ResidualAttentionBlock.swift:51-95) and the cached cross K/V projection
+// (MultiHeadAttention.swift:49-59).  Launch sequence per layer: LN -> fused QKV GEMM (V transposed in the
+// epilogue) -> flash attention -> out-proj GEMM (+bias +residual, fp32) -> LN -> MLP1 GEMM (+bias, erf-GELU)
+// -> MLP2 GEMM (+bias +residual).  The two convolutions are GEMMs over overlapping row windows (gemm.hip).
+#include "whisper.h"
+
+namespace {
+
+int gemm(mia_whisper* w, const GemmArgs& g) {
+  if (const char* e = mia_gemm_check(g)) return mia_fail(w->ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
+  if (mia_gemm_launch(g, w->dtype, w->ctx->stream) != 0) return mia_fail(w->ctx, MIA_ERR_DEVICE, "gemm launch failed");
+  return MIA_OK;
+}
+
+template <typename P>
+int alloc(mia_whisper* w, P*& p, size_t bytes, bool zero) {
+  void* q = nullptr;
+  if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess)
+    return mia_fail(w->ctx, MIA_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed for batch buffers", bytes);
+  w->allocs.push_back(q);
+  if (zero && hipMemsetAsync(q, 0, bytes, w->ctx->stream) != hipSuccess) return mia_fail(w->ctx, MIA_ERR_DEVICE, "memset failed");
+  p = (P*)q;
+  return MIA_OK;
+}
+
+}  // namespace
+
+// (Re)allocate every per-batch buffer for capacity B.  Buffers only grow; old ones are released at mia_whisper_free.
+int whisper_reserve(mia_whisper* w, int B) {
+  if (B <= w->cap_B) return MIA_OK;
+  MIA_HIP(w->ctx, hipStreamSynchronize(w->ctx->stream));
+  const mia_whisper_dims& d = w->dims;
+  const size_t D = d.n_audio_state, T = d.n_audio_ctx, H = d.n_audio_head, L = d.n_text_layer;
+  const size_t M = (size_t)B * T;
+  w->Tpad = (int)align_up(T, 64);
+  int rc;
+#define A(p, bytes, zero) if ((rc = alloc(w, p, (bytes), (zero))) != MIA_OK) return rc
+  A(w->mel_pad, ((size_t)B * (2 * T + 2) * d.n_mels + 256) * 2, true);
+  A(w->conv1_out, (size_t)B * (2 * T + 1) * D * 2, true);
+  A(w->x, M * D * 4, false);
+  A(w->h, M * D * 2, false);
+  A(w->qk, M * 2 * D * 2, false);
+  A(w->vt, (size_t)B * H * 64 * w->Tpad * 2, true);
+  A(w->att, M * D * 2, false);
+  A(w->g, M * 4 * D * 2, false);
+  A(w->feat, M * D * 2, false);
+  A(w->cross_k, L * M * D * 2, false);
+  A(w->cross_v, L * M * D * 2, false);
+  // decoder
+  const size_t C = d.n_text_ctx, V = d.n_vocab;
+  A(w->self_k, L * B * C * D * 2, true);
+  A(w->self_v, L * B * C * D * 2, true);
+  A(w->dx, (size_t)B * D * 4, false);
+  A(w->dh, (size_t)B * D * 2, false);
+  A(w->dq, (size_t)B * D * 2, false);
+  A(w->da, (size_t)B * D * 2, false);
+  A(w->dg, (size_t)B * 4 * D * 2, false);
+  A(w->partial, (size_t)16 * B * D * 4, false);
+  A(w->logits, (size_t)B * V * 4, false);
+  A(w->tokens, (size_t)B * C * 4, true);
+  A(w->n_gen, (size_t)B * 4, true);
+  A(w->finished, (size_t)B * 4, true);
+  A(w->last_ts, (size_t)B * 4, true);
+  A(w->out_n, (size_t)B * 4, true);
+  A(w->sum_logprob, (size_t)B * 4, true);
+  A(w->n_logprob, (size_t)B * 4, true);
+  A(w->no_speech, (size_t)B * 4, true);
+  A(w->uniforms, (size_t)B * C * 4, true);
+  A(w->out_tokens, (size_t)B * C * 4, true);
+  A(w->out_avg, (size_t)B * 4, true);
+  if (!w->suppress_bits) { A(w->suppress_bits, 2 * ((V + 31) / 32) * 4, true); }
+  if (!w->state) { A(w->state, sizeof(DecState), true); }
+#undef A
+  w->cap_B = B;
+  w->graph_valid = false;
+  return MIA_OK;
+}
+
+int whisper_encode_from_padded_mel(mia_whisper* w, int B) {
+  const mia_whisper_dims& d = w->dims;
+  const int D = d.n_audio_state, T = d.n_audio_ctx, H = d.n_audio_head, M = B * T;
+  hipStream_t s = w->ctx->stream;
+  int rc;
+  {  // conv1 + GELU: rows are overlapping windows of the zero-row-padded mel (stride n_mels, K = 3*n_mels)
+    GemmArgs g;
+    g.A = w->mel_pad; g.lda = d.n_mels; g.strideA = (int64_t)(2 * T + 2) * d.n_mels;
+    g.W = w->conv1.w; g.bias = w->conv1.b; g.act = MIA_ACT_GELU;
+    g.C = (uint16_t*)w->conv1_out + D; g.ldc = D; g.strideC = (int64_t)(2 * T + 1) * D;
+    g.M = 2 * T; g.N = D; g.K = w->kpad_conv1; g.batch = B;
+    if ((rc = gemm(w, g)) != MIA_OK) return rc;
+  }
+  {  // conv2 (stride 2) + GELU + positional embedding -> fp32 residual stream
+    GemmArgs g;
+    g.A = w->conv1_out; g.lda = 2 * D; g.strideA = (int64_t)(2 * T + 1) * D;
+    g.W = w->conv2.w; g.bias = w->conv2.b; g.act = MIA_ACT_GELU;
+    g.R = w->enc_pos; g.ldr = D; g.strideR = 0;
+    g.C = w->x; g.ldc = D; g.strideC = (int64_t)T * D; g.out_f32 = 1;
+    g.M = T; g.N = D; g.K = 3 * D; g.batch = B;
+    if ((rc = gemm(w, g)) != MIA_OK) return rc;
+  }
+  for (int l = 0; l < d.n_audio_layer; ++l) {
+    const EncBlockW& b = w->enc[l];
+    if (mia_norm_launch(w->x, D, b.attn_ln.g, b.attn_ln.b, w->h, D, M, D, 1e-5f, false, w->dtype, s)) return mia_fail(w->ctx, MIA_ERR_DEVICE, "norm launch failed");
+    {
+      GemmArgs g;
+      g.A = w->h; g.lda = D; g.W = b.qkv.w; g.bias = b.qkv.b;
+      g.C = w->qk; g.ldc = 2 * D; g.C2 = w->vt;
+      g.M = M; g.N = 3 * D; g.K = D; g.epi = MIA_EPI_QKV_VT; g.T = T; g.H = H; g.Tpad = w->Tpad;
+      if ((rc = gemm(w, g)) != MIA_OK) return rc;
+    }
+    if (const char* e = mia_enc_attention_check(B, T, H, w->Tpad, 2 * D, D)) return mia_fail(w->ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
+    if (mia_enc_attention_launch(w->qk, 2 * D, w->vt, w->att, D, B, T, H, w->Tpad, w->dtype, s)) return mia_fail(w->ctx, MIA_ERR_DEVICE, "attention launch failed");
+    {
+      GemmArgs g;
+      g.A = w->att; g.lda = D; g.W = b.out.w; g.bias = b.out.b;
+      g.R = w->x; g.ldr = D; g.C = w->x; g.ldc = D; g.out_f32 = 1;
+      g.M = M; g.N = D; g.K = D;
+      if ((rc = gemm(w, g)) != MIA_OK) return rc;
+    }
+    if (mia_norm_launch(w->x, D, b.mlp_ln.g, b.mlp_ln.b, w->h, D, M, D, 1e-5f, false, w->dtype, s)) return mia_fail(w->ctx, MIA_ERR_DEVICE, "norm launch failed");
+    {
+      GemmArgs g;
+      g.A = w->h; g.lda = D; g.W = b.mlp1.w; g.bias = b.mlp1.b; g.act = MIA_ACT_GELU;
+      g.C = w->g; g.ldc = 4 * D; g.M = M; g.N = 4 * D; g.K = D;
+      if ((rc = gemm(w, g)) != MIA_OK) return rc;
+    }
+    {
+      GemmArgs g;
+      g.A = w->g; g.lda = 4 * D; g.W = b.mlp2.w; g.bias = b.mlp2.b;
+      g.R = w->x; g.ldr = D; g.C = w->x; g.ldc = D; g.out_f32 = 1;
+      g.M = M; g.N = D; g.K = 4 * D;
+      if ((rc = gemm(w, g)) != MIA_OK) return rc;
+    }
+  }
+  if (mia_norm_launch(w->x, D, w->ln_post.g, w->ln_post.b, w->feat, D, M, D, 1e-5f, false, w->dtype, s)) return mia_fail(w->ctx, MIA_ERR_DEVICE, "norm launch failed");
+  // cross-attention K/V of every decoder layer, head-major [L][B][H][T][64]
+  for (int l = 0; l < d.n_text_layer; ++l) {
+    const DecBlockW& b = w->dec[l];
+    const size_t off = (size_t)l * w->cap_B * T * D;   // layer stride uses the capacity so buffers stay put when B varies
+    for (int kv = 0; kv < 2; ++kv) {
+      GemmArgs g;
+      g.A = w->feat; g.lda = D; g.W = kv ? b.cv.w : b.ck.w; g.bias = kv ? b.cv.b : b.ck.b;
+      g.C = (uint16_t*)(kv ? w->cross_v : w->cross_k) + off;
+      g.M = M; g.N = D; g.K = D; g.epi = MIA_EPI_HEADMAJOR; g.T = T; g.H = H;
+      if ((rc = gemm(w, g)) != MIA_OK) return rc;
+    }
+  }
+  w->cur_B = B;
+  MIA_HIP(w->ctx, hipGetLastError());
+  return MIA_OK;
+}
+
+// dense [B][2T][n_mels] (compute dtype) -> zero-row-padded layout
+static __global__ void pad_mel_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t rows, int n_mels, int B) {
+  const int64_t per = rows * n_mels;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < per * B; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / per, r = e - b * per;
+    out[b * (rows + 2) * n_mels + n_mels + r] = in[e];
+  }
+}
+
+extern "C" int mia_whisper_encode(mia_whisper* w, const void* mel, int B, int mem) {
+  if (!w) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = w->ctx;
+  MIA_CHECK_ARG(ctx, mel && B > 0, "whisper_encode: mel must be non-null and B > 0");
+  MIA_CHECK_ARG(ctx, mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE, "whisper_encode: bad mem %d", mem);
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = whisper_reserve(w, B);
+  if (rc != MIA_OK) return rc;
+  const int64_t rows = 2 * (int64_t)w->dims.n_audio_ctx;
+  const size_t bytes = (size_t)B * rows * w->dims.n_mels * 2;
+  const uint16_t* src = (const uint16_t*)mel;
+  if (mem == MIA_MEM_HOST) {
+    void* ws = mia_workspace(ctx, bytes);
+    if (!ws) return MIA_ERR_OUT_OF_MEMORY;
+    MIA_HIP(ctx, hipMemcpyAsync(ws, mel, bytes, hipMemcpyHostToDevice, ctx->stream));
+    src = (const uint16_t*)ws;
+  }
+  hipLaunchKernelGGL(pad_mel_kernel, dim3(1024), dim3(256), 0, ctx->stream, src, (uint16_t*)w->mel_pad, rows, w->dims.n_mels, B);
+  return whisper_encode_from_padded_mel(w, B);
+}
+
+template <typename T>
+static __global__ void cvt16_to_f32(const uint16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) out[e] = T::to_f32(in[e]);
+}
+
+extern "C" int mia_whisper_get_audio_features(mia_whisper* w, void* out, int dtype, int mem) {
+  if (!w) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = w->ctx;
+  MIA_CHECK_ARG(ctx, out && w->cur_B > 0, "get_audio_features: no encode has run (or null out)");
+  MIA_CHECK_ARG(ctx, dtype == MIA_F32 || dtype == w->dtype, "get_audio_features: dtype must be MIA_F32 or the compute dtype");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t n = (int64_t)w->cur_B * w->dims.n_audio_ctx * w->dims.n_audio_state;
+  const void* src = w->feat;
+  size_t bytes = (size_t)n * 2;
+  if (dtype == MIA_F32) {
+    bytes = (size_t)n * 4;
+    float* dst = mem == MIA_MEM_DEVICE ? (float*)out : (float*)mia_workspace(ctx, bytes);
+    if (!dst) return MIA_ERR_OUT_OF_MEMORY;
+    if (w->dtype == MIA_F16) hipLaunchKernelGGL(cvt16_to_f32<F16>, dim3(1024), dim3(256), 0, ctx->stream, (const uint16_t*)w->feat, dst, n);
+    else hipLaunchKernelGGL(cvt16_to_f32<BF16>, dim3(1024), dim3(256), 0, ctx->stream, (const uint16_t*)w->feat, dst, n);
+    if (mem == MIA_MEM_DEVICE) return MIA_OK;
+    src = dst;
+  }
+  MIA_HIP(ctx, hipMemcpyAsync(out, src, bytes, mem == MIA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  if (mem == MIA_MEM_HOST) MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MIA_OK;
+}

@@ -1,0 +1,432 @@
+"""ORACLE (test infrastructure, not product code) -- CPU restatement of the reference Whisper network and greedy decoder.
+
+parity unpinned: the reference holds no tensor-level golden vectors for this path; this file
+restates the Swift source line by line in fp32 (torch CPU for the matmuls) and is cross-checked against the
+independent `transformers` Whisper implementation in tests/test_oracle_whisper.py.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Follows (paths relative to /root/reference/package/STT/Whisper):
+  Layers/AudioEncoder.swift:43-68,78-96        encoder forward, sinusoids
+  Layers/MultiHeadAttention.swift:40-135       q/k/v projections (key has no bias), d^-1/4 scaling of q and k,
+                                               additive mask slice, fp32 softmax, output projection
+  Layers/ResidualAttentionBlock.swift:51-95    pre-LN block order
+  Layers/TextDecoder.swift:38-42,53-96         causal -inf mask, learned positions by cache offset, tied logits
+  WhisperDecoding.swift:96-389                 GreedyDecoder.decode (initial tokens, rules, argmax, log-probs)
+  WhisperModel.swift:121-128,223-260           vocabulary arithmetic, detectLanguage
+  WhisperTokenizer.swift:72-96,377-396         special-token ids, sotSequence
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+torch.set_grad_enabled(False)
+
+
+@dataclass
+class ModelDimensions:
+    """WhisperConfig.swift:9-86"""
+    n_mels: int
+    n_audio_ctx: int
+    n_audio_state: int
+    n_audio_head: int
+    n_audio_layer: int
+    n_vocab: int
+    n_text_ctx: int
+    n_text_state: int
+    n_text_head: int
+    n_text_layer: int
+
+    def astuple(self):
+        return (self.n_mels, self.n_audio_ctx, self.n_audio_state, self.n_audio_head, self.n_audio_layer,
+                self.n_vocab, self.n_text_ctx, self.n_text_state, self.n_text_head, self.n_text_layer)
+
+
+# public OpenAI dims: not in the reference tree, read from config.json at load time there
+DIMS = {
+    "tiny.en": ModelDimensions(80, 1500, 384, 6, 4, 51864, 448, 384, 6, 4),
+    "large-v3-turbo": ModelDimensions(128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 4),
+    "large-v3": ModelDimensions(128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 32),
+    # reduced-size layouts for tests (same vocabulary arithmetic as tiny.en / multilingual)
+    "micro.en": ModelDimensions(80, 100, 128, 2, 2, 51864, 448, 128, 2, 2),
+    "micro": ModelDimensions(128, 100, 128, 2, 2, 51866, 448, 128, 2, 2),
+}
+
+
+@dataclass
+class SpecialTokens:
+    """WhisperTokenizer.swift:72-96 id arithmetic."""
+    eot: int
+    sot: int
+    translate: int
+    transcribe: int
+    sot_lm: int
+    sot_prev: int
+    no_speech: int
+    no_timestamps: int
+    timestamp_begin: int
+    is_multilingual: bool
+    num_languages: int
+
+    @staticmethod
+    def for_vocab(n_vocab: int) -> "SpecialTokens":
+        multilingual = n_vocab >= 51865                      # WhisperModel.swift:121-123
+        num_languages = n_vocab - 51765 - (1 if multilingual else 0)   # :126-128
+        nxt = 50257 if multilingual else 50256
+        eot = nxt; nxt += 1
+        sot = nxt; nxt += 1
+        nxt += num_languages
+        translate = nxt; nxt += 1
+        transcribe = nxt; nxt += 1
+        sot_lm = nxt; nxt += 1
+        sot_prev = nxt; nxt += 1
+        no_speech = nxt; nxt += 1
+        no_timestamps = nxt; nxt += 1
+        return SpecialTokens(eot, sot, translate, transcribe, sot_lm, sot_prev, no_speech, no_timestamps, nxt,
+                             multilingual, num_languages)
+
+    def sot_sequence(self, language_index: int | None = 0, task: str = "transcribe") -> list[int]:
+        """WhisperTokenizer.swift:377-396 (language token = sot + 1 + index)."""
+        seq = [self.sot]
+        if not self.is_multilingual:
+            return seq
+        if language_index is not None:
+            seq.append(self.sot + 1 + language_index)
+        seq.append(self.transcribe if task == "transcribe" else self.translate)
+        return seq
+
+
+def synthetic_suppress_list(st: SpecialTokens, n: int = 90, seed: int = 11) -> list[int]:
+    """The real non-speech list needs the tiktoken vocabulary (WhisperTokenizer.swift:489-532), absent offline:
+    a fixed synthetic list of text ids + the specials GreedyDecoder always adds (:190-198)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ids = sorted(int(i) for i in rng.choice(st.eot, size=n, replace=False))
+    return ids + [st.transcribe, st.translate, st.sot, st.sot_prev, st.sot_lm, st.no_speech]
+
+
+def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.ndarray:
+    """AudioEncoder.swift:78-96 in fp32."""
+    inc = np.float32(math.log(max_timescale)) / np.float32(channels // 2 - 1)
+    inv = np.exp(-inc * np.arange(channels // 2, dtype=np.float32)).astype(np.float32)
+    st = (np.arange(length, dtype=np.float32)[:, None] * inv[None, :]).astype(np.float32)
+    return np.concatenate([np.sin(st), np.cos(st)], axis=1).astype(np.float32)
+
+
+def weight_names(d: ModelDimensions) -> dict[str, tuple]:
+    """Reference checkpoint schema (Module property paths) -> shapes."""
+    D, M = d.n_audio_state, d.n_mels
+    out: dict[str, tuple] = {
+        "encoder.conv1.weight": (D, 3, M), "encoder.conv1.bias": (D,),
+        "encoder.conv2.weight": (D, 3, D), "encoder.conv2.bias": (D,),
+        "encoder.ln_post.weight": (D,), "encoder.ln_post.bias": (D,),
+        "decoder.token_embedding.weight": (d.n_vocab, D),
+        "decoder.positional_embedding": (d.n_text_ctx, D),
+        "decoder.ln.weight": (D,), "decoder.ln.bias": (D,),
+    }
+
+    def block(p, cross):
+        names = {}
+        for a in (["attn"] + (["cross_attn"] if cross else [])):
+            names[f"{p}.{a}.query.weight"] = (D, D); names[f"{p}.{a}.query.bias"] = (D,)
+            names[f"{p}.{a}.key.weight"] = (D, D)
+            names[f"{p}.{a}.value.weight"] = (D, D); names[f"{p}.{a}.value.bias"] = (D,)
+            names[f"{p}.{a}.out.weight"] = (D, D); names[f"{p}.{a}.out.bias"] = (D,)
+            names[f"{p}.{a}_ln.weight"] = (D,); names[f"{p}.{a}_ln.bias"] = (D,)
+        names[f"{p}.mlp1.weight"] = (4 * D, D); names[f"{p}.mlp1.bias"] = (4 * D,)
+        names[f"{p}.mlp2.weight"] = (D, 4 * D); names[f"{p}.mlp2.bias"] = (D,)
+        names[f"{p}.mlp_ln.weight"] = (D,); names[f"{p}.mlp_ln.bias"] = (D,)
+        return names
+
+    for l in range(d.n_audio_layer):
+        out.update(block(f"encoder.blocks.{l}", False))
+    for l in range(d.n_text_layer):
+        out.update(block(f"decoder.blocks.{l}", True))
+    return out
+
+
+def _key_seed(name: str, seed: int) -> int:
+    h = 2166136261
+    for ch in name.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return (h + seed * 0x9E3779B1) & 0xFFFFFFFF
+
+
+def synthetic_weights(d: ModelDimensions, seed: int = 0, style: str = "lecun", round_to: str | None = None) -> dict[str, np.ndarray]:
+    """Seeded random-init checkpoint with the reference's key schema.
+    style 'survey': N(0, 0.02^2) matrices, LN gamma 1 beta 0.
+    style 'lecun' : N(0, 1/fan_in) matrices, small random biases / LN affine -- O(1) activations, harder test.
+    round_to: None | 'bf16' | 'f16' rounds every tensor to that storage type (still returned as fp32)."""
+    w: dict[str, np.ndarray] = {}
+    for name, shape in weight_names(d).items():
+        rng = np.random.Generator(np.random.PCG64(_key_seed(name, seed)))
+        is_ln = "_ln." in name or ".ln." in name or "ln_post" in name
+        if is_ln and name.endswith(".weight"):
+            a = np.ones(shape, np.float32) if style == "survey" else (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif name.endswith(".bias"):
+            a = np.zeros(shape, np.float32) if style == "survey" else (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            if style == "survey":
+                std = 0.02
+            elif name == "decoder.token_embedding.weight":
+                std = 1.0 / math.sqrt(shape[-1]) * 4.0     # spread logits: larger argmax margins
+            elif name == "decoder.positional_embedding":
+                std = 0.02
+            else:
+                fan_in = int(np.prod(shape[1:]))
+                std = 1.0 / math.sqrt(fan_in)
+            a = (std * rng.standard_normal(shape)).astype(np.float32)
+        w[name] = round_array(a, round_to)
+    return w
+
+
+def round_array(a: np.ndarray, kind: str | None) -> np.ndarray:
+    if kind is None or kind == "f32":
+        return np.ascontiguousarray(a, np.float32)
+    t = torch.from_numpy(np.ascontiguousarray(a, np.float32))
+    if kind == "bf16":
+        return t.to(torch.bfloat16).to(torch.float32).numpy()
+    if kind == "f16":
+        return t.to(torch.float16).to(torch.float32).numpy()
+    raise ValueError(kind)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32))
+
+
+def _linear(x, w, b=None):
+    y = x @ w.t()
+    return y + b if b is not None else y
+
+
+def _layer_norm(x, g, b, eps=1e-5):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), g, b, eps)
+
+
+def _gelu(x):
+    return torch.nn.functional.gelu(x)      # exact erf form == MLXNN GELU()
+
+
+def _conv1d_cl(x, w, b, stride):
+    """MLX Conv1d: input [B,L,Cin] channels-last, weight [Cout,K,Cin], padding 1."""
+    y = torch.nn.functional.conv1d(x.transpose(1, 2), w.permute(0, 2, 1), b, stride=stride, padding=1)
+    return y.transpose(1, 2)
+
+
+class WhisperOracle:
+    """fp32 restatement of WhisperModel (encoder + decoder)."""
+
+    def __init__(self, dims: ModelDimensions, weights: dict[str, np.ndarray], threads: int | None = None):
+        self.dims = dims
+        self.w = {k: _t(v) for k, v in weights.items()}
+        if "encoder.positional_embedding" not in self.w:
+            self.w["encoder.positional_embedding"] = _t(sinusoids(dims.n_audio_ctx, dims.n_audio_state))
+        if threads:
+            torch.set_num_threads(threads)
+        n = dims.n_text_ctx
+        idx = torch.arange(n)
+        self.mask = torch.where(idx[:, None] < idx[None, :], torch.tensor(-float("inf")), torch.tensor(0.0))  # TextDecoder.swift:38-42
+
+    # ---- MultiHeadAttention.swift:85-135
+    def _qkv_attention(self, q, k, v, n_head, mask=None, offset=0):
+        B, n_ctx, n_state = q.shape
+        scale = float((n_state // n_head)) ** -0.25
+        qh = q.reshape(B, n_ctx, n_head, -1).permute(0, 2, 1, 3) * scale
+        k_ctx = k.shape[1]
+        kh = k.reshape(B, k_ctx, n_head, -1).permute(0, 2, 3, 1) * scale
+        vh = v.reshape(B, k_ctx, n_head, -1).permute(0, 2, 1, 3)
+        qk = qh @ kh
+        if mask is not None:
+            qk = qk + mask[offset:offset + n_ctx, :k_ctx]
+        wts = torch.softmax(qk, dim=-1)
+        out = (wts @ vh).permute(0, 2, 1, 3).reshape(B, n_ctx, n_state)
+        return out, qk
+
+    def _attn(self, p, x, n_head, xa=None, mask=None, kv_cache=None, offset=0):
+        W = self.w
+        q = _linear(x, W[p + ".query.weight"], W[p + ".query.bias"])
+        if xa is not None:
+            if kv_cache is not None:
+                k, v = kv_cache
+            else:
+                k = _linear(xa, W[p + ".key.weight"])
+                v = _linear(xa, W[p + ".value.weight"], W[p + ".value.bias"])
+        else:
+            k = _linear(x, W[p + ".key.weight"])
+            v = _linear(x, W[p + ".value.weight"], W[p + ".value.bias"])
+            if kv_cache is not None:
+                k = torch.cat([kv_cache[0], k], dim=1)
+                v = torch.cat([kv_cache[1], v], dim=1)
+        wv, qk = self._qkv_attention(q, k, v, n_head, mask, offset)
+        return _linear(wv, W[p + ".out.weight"], W[p + ".out.bias"]), (k, v), qk
+
+    # ---- ResidualAttentionBlock.swift:51-95
+    def _block(self, p, x, n_head, xa=None, mask=None, kv_cache=None, offset=0):
+        W = self.w
+        self_kv = kv_cache[0] if kv_cache else None
+        cross_kv = kv_cache[1] if kv_cache else None
+        y, new_self, _ = self._attn(p + ".attn", _layer_norm(x, W[p + ".attn_ln.weight"], W[p + ".attn_ln.bias"]), n_head,
+                                    mask=mask, kv_cache=self_kv, offset=offset)
+        x = x + y
+        new_cross = cross_kv
+        if xa is not None:
+            y, new_cross, _ = self._attn(p + ".cross_attn", _layer_norm(x, W[p + ".cross_attn_ln.weight"], W[p + ".cross_attn_ln.bias"]),
+                                         n_head, xa=xa, kv_cache=cross_kv)
+            x = x + y
+        h = _layer_norm(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"])
+        x = x + _linear(_gelu(_linear(h, W[p + ".mlp1.weight"], W[p + ".mlp1.bias"])), W[p + ".mlp2.weight"], W[p + ".mlp2.bias"])
+        return x, (new_self, new_cross)
+
+    # ---- AudioEncoder.swift:43-68
+    def encode(self, mel: np.ndarray) -> torch.Tensor:
+        """mel [B, 2*n_audio_ctx, n_mels] -> [B, n_audio_ctx, n_audio_state]."""
+        W, d = self.w, self.dims
+        x = _t(mel)
+        x = _gelu(_conv1d_cl(x, W["encoder.conv1.weight"], W["encoder.conv1.bias"], 1))
+        x = _gelu(_conv1d_cl(x, W["encoder.conv2.weight"], W["encoder.conv2.bias"], 2))
+        x = x + W["encoder.positional_embedding"][:x.shape[1]]
+        for l in range(d.n_audio_layer):
+            x, _ = self._block(f"encoder.blocks.{l}", x, d.n_audio_head)
+        return _layer_norm(x, W["encoder.ln_post.weight"], W["encoder.ln_post.bias"])
+
+    # ---- TextDecoder.swift:53-96
+    def decode(self, tokens: list[int] | np.ndarray, xa: torch.Tensor, kv_cache=None):
+        W, d = self.w, self.dims
+        tok = torch.as_tensor(np.asarray(tokens, np.int64)).reshape(1, -1)
+        offset = kv_cache[0][0][0].shape[1] if kv_cache is not None and kv_cache[0][0] is not None else 0
+        n = tok.shape[-1]
+        x = W["decoder.token_embedding.weight"][tok] + W["decoder.positional_embedding"][offset:offset + n]
+        new_cache = []
+        for l in range(d.n_text_layer):
+            x, c = self._block(f"decoder.blocks.{l}", x, d.n_text_head, xa=xa, mask=self.mask,
+                               kv_cache=kv_cache[l] if kv_cache is not None else None, offset=offset)
+            new_cache.append(c)
+        x = _layer_norm(x, W["decoder.ln.weight"], W["decoder.ln.bias"])
+        return x @ W["decoder.token_embedding.weight"].t(), new_cache
+
+    # ---- WhisperModel.swift:223-260
+    def detect_language(self, xa: torch.Tensor, st: SpecialTokens):
+        logits, _ = self.decode([st.sot], xa)
+        ll = logits[0, 0, st.sot + 1: st.sot + 1 + st.num_languages]
+        probs = torch.softmax(ll, dim=-1)
+        i = int(torch.argmax(probs))
+        return i, float(probs[i])
+
+
+@dataclass
+class DecodingOptions:
+    """WhisperDecoding.swift:14-51 (language as an index; tokenizer outputs passed as integer tables)."""
+    task: str = "transcribe"
+    language_index: int | None = 0
+    temperature: float = 0.0
+    max_tokens: int = 448
+    timestamps: bool = True
+    prompt: list[int] = field(default_factory=list)
+    suppress_ids: list[int] = field(default_factory=list)   # nonSpeechTokens + specials (:190-198)
+    blank_ids: list[int] = field(default_factory=list)      # tokenizer.encode(" ") (:201-206)
+    max_new_tokens: int = 0                                 # benchmarking aid (not in the reference)
+    max_initial_timestamp_index: int = 50
+
+
+@dataclass
+class DecodingResult:
+    tokens: list[int]
+    avg_logprob: float
+    no_speech_prob: float
+    margins: list[float]          # oracle-only diagnostic: top-1 minus top-2 filtered logit at every step
+    initial_tokens: list[int]
+
+
+def initial_tokens(st: SpecialTokens, o: DecodingOptions) -> tuple[list[int], int]:
+    """WhisperDecoding.swift:104-122.  Returns (tokens, sot_index)."""
+    toks: list[int] = []
+    if o.prompt:
+        toks.append(st.sot_prev)
+        toks.extend(o.prompt)
+    sot_index = len(toks)
+    toks.extend(st.sot_sequence(o.language_index, o.task))
+    if not o.timestamps:
+        toks.append(st.no_timestamps)
+    return toks, sot_index
+
+
+def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: DecodingOptions) -> DecodingResult:
+    """GreedyDecoder.decode (WhisperDecoding.swift:96-389) for ONE clip (xa [1, n_audio_ctx, D]), temperature 0."""
+    assert o.temperature == 0.0, "the reference's T>0 path uses an unseeded system RNG; parity is defined at T=0 only"
+    V = model.dims.n_vocab
+    tokens, sot_index = initial_tokens(st, o)
+    init = list(tokens)
+    initial_count = len(tokens)
+    max_generate = o.max_tokens - initial_count
+    if o.max_new_tokens > 0:
+        max_generate = min(max_generate, o.max_new_tokens)
+    kv = None
+    sum_lp, count, no_speech_prob = 0.0, 0, 0.0
+    margins: list[float] = []
+    NEG = -float("inf")
+    idx = torch.arange(V)
+    for it in range(max_generate):
+        feed = tokens if kv is None else tokens[-1:]
+        logits, kv = model.decode(feed, xa, kv)
+        if it == 0:
+            probs = torch.softmax(logits[0, sot_index], dim=-1)          # :158-169
+            no_speech_prob = float(probs[st.no_speech])
+        last = logits[0, -1].clone()
+        num_generated = len(tokens) - initial_count
+        sup = list(o.suppress_ids)                                       # :190-198 (caller passes the full list)
+        if it == 0:
+            sup = sup + list(o.blank_ids) + [st.eot]                     # :201-206
+        base = torch.zeros(V)
+        for t in sup:
+            if t < V:
+                base[t] = NEG
+        ts_mask = torch.zeros(V)
+        tsb = st.timestamp_begin
+        if o.timestamps:
+            ts_mask[st.no_timestamps] = NEG
+            last_was_ts = num_generated >= 1 and tokens[-1] >= tsb
+            penult_was_ts = num_generated < 2 or tokens[-2] >= tsb
+            if last_was_ts:
+                if penult_was_ts:
+                    ts_mask[idx >= tsb] = NEG
+                else:
+                    ts_mask[idx < st.eot] = NEG
+            gen = tokens[len(tokens) - num_generated:] if num_generated else []
+            ts_vals = [t for t in gen if t > tsb]                        # strict > (:254-256)
+            if ts_vals:
+                lt = ts_vals[-1] + (1 if penult_was_ts else 0)
+                ts_mask[(idx >= tsb) & (idx < lt)] = NEG
+            if num_generated == 0:
+                ts_mask[idx < tsb] = NEG
+                last_allowed = tsb + o.max_initial_timestamp_index
+                if last_allowed < V:
+                    ts_mask[idx > last_allowed] = NEG
+        force_ts = False
+        if o.timestamps and num_generated > 0:                           # :299-322 on RAW logits
+            lp = last - torch.logsumexp(last, dim=-1, keepdim=True)
+            ts_lp = torch.logsumexp(lp[tsb:], dim=-1)
+            max_text = lp[:tsb].max()
+            if float(ts_lp) > float(max_text):
+                force_ts = True
+        if force_ts:
+            ts_mask[idx < tsb] = NEG
+        last = last + torch.minimum(base, ts_mask)
+        nxt = int(torch.argmax(last))
+        top2 = torch.topk(last, 2).values
+        margins.append(float(top2[0] - top2[1]))
+        if nxt != st.eot:                                                # :345-350
+            lps = torch.log(torch.softmax(last, dim=-1))
+            sum_lp += float(lps[nxt])
+            count += 1
+        tokens.append(nxt)
+        if nxt == st.eot:
+            break
+    avg = sum_lp / count if count > 0 else 0.0
+    gen = tokens[initial_count:]
+    if st.eot in gen:
+        gen = gen[:gen.index(st.eot)]
+    return DecodingResult(gen, avg, no_speech_prob, margins, init)

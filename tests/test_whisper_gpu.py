@@ -1,0 +1,148 @@
+"""GPU parity: HIP Whisper (encoder, greedy decoder) through the C ABI vs the fp32 CPU oracle, reduced dims.
+
+Both sides use the same seeded synthetic checkpoint, pre-rounded to the 16-bit storage type so only activation
+precision and accumulation order differ.  Tolerances (stated, checked below):
+  audio features (post-LayerNorm, O(1)):  max |err| <= 0.06 (bf16) / 0.01 (f16); mean |err| <= 0.008 / 0.0015
+  greedy token ids: bit-exact, except that a first divergence is tolerated only where the oracle's own top-1/top-2
+  margin is below MARGIN_TOL (a near-tie that 16-bit activations cannot resolve); the golden case must match fully.
+"""
+import numpy as np
+import pytest
+
+from oracle import logmel as OL
+from oracle import whisper as OW
+
+pytestmark = pytest.mark.gpu
+
+MARGIN_TOL = {"bf16": 0.15, "f16": 0.03}
+
+
+def _dt(name):
+    import mlx_swift_audio_amd as m
+    return m.BF16 if name == "bf16" else m.F16
+
+
+def _models(ctx, dims_name, dtype_name, seed):
+    from mlx_swift_audio_amd import whisper as HW
+    dims = OW.DIMS[dims_name]
+    weights = OW.synthetic_weights(dims, seed=seed, round_to=dtype_name)
+    oracle = OW.WhisperOracle(dims, weights)
+    model = HW.WhisperModel.load(ctx, dims, weights, _dt(dtype_name))
+    return dims, oracle, model
+
+
+def _mel(dims, B, seed, dtype_name):
+    rng = np.random.default_rng(seed)
+    mel = (0.5 * rng.standard_normal((B, 2 * dims.n_audio_ctx, dims.n_mels))).astype(np.float32)
+    return OW.round_array(mel, dtype_name)      # the window is cast to 16 bit before the encoder (WhisperSTT.swift:182)
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+@pytest.mark.parametrize("dims_name", ["micro.en", "micro"])
+def test_encoder_matches_oracle(ctx, dims_name, dtype_name):
+    dims, oracle, model = _models(ctx, dims_name, dtype_name, seed=5)
+    mel = _mel(dims, 3, 0, dtype_name)
+    model.encode(mel)
+    got = model.audio_features()
+    ref = oracle.encode(mel).numpy()
+    err = np.abs(got - ref)
+    mx, mean = (0.06, 0.008) if dtype_name == "bf16" else (0.01, 0.0015)
+    assert got.shape == ref.shape
+    assert err.max() <= mx and err.mean() <= mean, (err.max(), err.mean())
+    model.close()
+
+
+def _compare(tokens, ref, tol):
+    n = min(len(tokens), len(ref.tokens))
+    for i in range(n):
+        if tokens[i] != ref.tokens[i]:
+            return i, ref.margins[i]
+    if len(tokens) != len(ref.tokens):
+        return n, ref.margins[n] if n < len(ref.margins) else 0.0
+    return None, None
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+@pytest.mark.parametrize("timestamps", [True, False])
+def test_greedy_decode_matches_oracle(ctx, dtype_name, timestamps):
+    from mlx_swift_audio_amd import whisper as HW
+    dims, oracle, model = _models(ctx, "micro.en", dtype_name, seed=5)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    sup = OW.synthetic_suppress_list(st)
+    B = 4
+    mel = _mel(dims, B, 1, dtype_name)
+    o = HW.DecodingOptions(timestamps=timestamps, suppress_ids=sup, blank_ids=[220, 50256 - 1], max_new_tokens=40)
+    res = HW.GreedyDecoder(model, o).decode(mel)
+    oo = OW.DecodingOptions(timestamps=timestamps, suppress_ids=sup, blank_ids=[220, 50256 - 1], max_new_tokens=40)
+    xa = oracle.encode(mel)
+    full = 0
+    for b in range(B):
+        ref = OW.greedy_decode(oracle, st, xa[b:b + 1], oo)
+        i, margin = _compare(res[b].tokens, ref, MARGIN_TOL[dtype_name])
+        if i is None:
+            full += 1
+            np.testing.assert_allclose(res[b].avg_logprob, ref.avg_logprob, atol=0.05, rtol=0.02)
+        else:
+            assert margin < MARGIN_TOL[dtype_name], f"clip {b}: diverged at step {i} where the oracle margin is {margin}"
+        np.testing.assert_allclose(res[b].no_speech_prob, ref.no_speech_prob, rtol=0.1, atol=1e-6)
+    assert full >= 1, "no clip matched the oracle end to end"
+    model.close()
+
+
+def test_prompt_conditioning_and_multilingual(ctx):
+    """[sot_prev]+prompt prefix (WhisperDecoding.swift:104-112), multilingual sot sequence, language detection."""
+    from mlx_swift_audio_amd import whisper as HW
+    dims, oracle, model = _models(ctx, "micro", "f16", seed=9)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    mel = _mel(dims, 2, 3, "f16")
+    prompt = [1000, 2000, 3000, 4000, 5000]
+    o = HW.DecodingOptions(language_index=7, prompt=prompt, suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=16)
+    res = HW.GreedyDecoder(model, o).decode(mel)
+    oo = OW.DecodingOptions(language_index=7, prompt=prompt, suppress_ids=o.suppress_ids, blank_ids=[220], max_new_tokens=16)
+    xa = oracle.encode(mel)
+    for b in range(2):
+        ref = OW.greedy_decode(oracle, st, xa[b:b + 1], oo)
+        assert ref.initial_tokens == [st.sot_prev] + prompt + [st.sot, st.sot + 8, st.transcribe]
+        i, margin = _compare(res[b].tokens, ref, MARGIN_TOL["f16"])
+        assert i is None or margin < MARGIN_TOL["f16"], (b, i, margin)
+    langs = model.detect_language()
+    for b in range(2):
+        li, lp = oracle.detect_language(xa[b:b + 1], st)
+        assert langs[b][0] == li and abs(langs[b][1] - lp) < 0.02
+    model.close()
+
+
+def test_transcribe_windows_end_to_end(ctx):
+    """pcm -> log-mel -> encoder -> greedy decode in one call equals the staged path."""
+    from mlx_swift_audio_amd import audio as A
+    from mlx_swift_audio_amd import whisper as HW
+    dims, oracle, model = _models(ctx, "micro.en", "f16", seed=5)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    n = dims.n_audio_ctx * 2 * 160                      # one (reduced) window of samples
+    clips = [OL.synth_clip(i, n) for i in range(3)]
+    o = HW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=12)
+    fused = model.transcribe_windows(clips, o, pad_right=n)
+    mel = A.whisper_log_mel_spectrogram(ctx, clips, dims.n_mels, padding=n, n_frames=2 * dims.n_audio_ctx)
+    staged = HW.GreedyDecoder(model, o).decode(mel)
+    for a, b in zip(fused, staged):
+        assert a.tokens == b.tokens
+        assert a.no_speech_prob == pytest.approx(b.no_speech_prob, rel=1e-5)
+    model.close()
+
+
+def test_error_paths(ctx):
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import whisper as HW
+    dims = OW.DIMS["micro.en"]
+    weights = OW.synthetic_weights(dims, seed=1)
+    bad = dict(weights)
+    del bad["decoder.ln.bias"]
+    with pytest.raises(m.MiaError):
+        HW.WhisperModel.load(ctx, dims, bad)
+    model = HW.WhisperModel.load(ctx, dims, weights)
+    with pytest.raises(m.MiaError):
+        model.encode(np.zeros((1, 10, dims.n_mels), np.float32))
+    model.encode(np.zeros((1, 2 * dims.n_audio_ctx, dims.n_mels), np.float32))
+    with pytest.raises(m.MiaError):                      # prompt longer than the budget: the Swift would trap (appendix A3)
+        model.decode_greedy(HW.DecodingOptions(prompt=list(range(500)), max_tokens=448))
+    model.close()
