@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native speech-inference hot path.
+
+Metric (BASELINE.json): audio-seconds transcribed per wall-second, Whisper large-v3-turbo, bf16, 32 x 30 s synthetic
+clips per GPU (weak scaling: every rank transcribes its own 32 clips, then ONE RCCL all-gather of the token ids).
+A "step" = one pass of the hot path over the batch: log-mel -> encoder -> cross-KV -> greedy decode (one 30 s window per
+clip, T=0, timestamps on, max_tokens 448) with pcm already resident in HBM.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel class, measured
+live with HIP events on the library's stream) and `cpu_baseline` (the fp32 CPU restatement, oracle/, timed on the
+host cores of this box on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(dims_name: str, seed: int, n_threads: int, max_new_tokens: int):
+    """fp32 CPU restatement of the same pipeline on ONE of the clips (bounded sample), all stages timed."""
+    import torch
+    from oracle import logmel as OL
+    from oracle import whisper as OW
+    torch.set_num_threads(n_threads)
+    dims = OW.DIMS[dims_name]
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    weights = OW.synthetic_weights(dims, seed=seed, style="survey", round_to="bf16")
+    model = OW.WhisperOracle(dims, weights)
+    clip = OL.synth_clip(0)
+    t0 = time.perf_counter()
+    mel = OL.whisper_log_mel_spectrogram(clip, dims.n_mels, padding=OL.N_SAMPLES)[:OL.N_FRAMES]
+    mel = OW.round_array(mel, "bf16")[None]
+    t1 = time.perf_counter()
+    xa = model.encode(mel)
+    t2 = time.perf_counter()
+    o = OW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=max_new_tokens)
+    r = OW.greedy_decode(model, st, xa, o)
+    t3 = time.perf_counter()
+    n_tok = max(len(r.margins), 1)
+    full_tokens = dims.n_text_ctx - len(r.initial_tokens)
+    # decode is linear in the number of steps: scale the measured steps to the full 445-step budget the GPU run executes
+    t_dec_full = (t3 - t2) * full_tokens / n_tok
+    total = (t1 - t0) + (t2 - t1) + t_dec_full
+    return {"value": 30.0 / total, "unit": "audio-sec/s", "cores": n_threads, "kind": "port",
+            "sample": (f"1 of the 30 s clips, fp32 torch-CPU restatement (oracle/): log-mel {t1 - t0:.2f}s + encoder {t2 - t1:.2f}s + "
+                       f"{n_tok} greedy steps {t3 - t2:.2f}s scaled to {full_tokens} steps")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="large-v3-turbo")
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--max-new-tokens", type=int, default=0, help="cap generated tokens per clip (0 = full 448 budget)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=24, help="greedy steps actually run by the CPU baseline")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import synthetic as S
+    from mlx_swift_audio_amd import whisper as HW
+
+    dims = S.DIMS[args.model]
+    dtype = m.BF16 if args.dtype == "bf16" else m.F16
+    # one non-default HIP stream shared by torch and the library (graph capture is illegal on the legacy default stream)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx = m.Context(local_rank, stream=stream.cuda_stream)
+
+    t0 = time.time()
+    weights = S.synthetic_weights(dims, seed=args.seed, style="survey")
+    log(f"[bench] synthetic {args.model} checkpoint generated in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    model = HW.WhisperModel.load(ctx, dims, weights, dtype)
+    del weights
+    log(f"[bench] weights uploaded in {time.time() - t0:.1f}s")
+
+    B = args.batch
+    clips = np.stack([S.synth_clip(rank * B + i) for i in range(B)])
+    pcm = torch.from_numpy(clips).cuda()
+    offs = np.arange(B + 1, dtype=np.int64) * clips.shape[1]
+    st = model.special
+    opts = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=args.max_new_tokens)
+    tokens = torch.zeros((B, opts.max_tokens), dtype=torch.int32, device="cuda")
+    n_tok = torch.zeros(B, dtype=torch.int32, device="cuda")
+    avg = torch.zeros(B, dtype=torch.float32, device="cuda")
+    nsp = torch.zeros(B, dtype=torch.float32, device="cuda")
+    gathered = [torch.zeros_like(tokens) for _ in range(world)] if world > 1 else None
+
+    def step():
+        model.transcribe_windows_device(pcm.data_ptr(), offs, opts, tokens.data_ptr(), n_tok.data_ptr(), avg.data_ptr(), nsp.data_ptr())
+        if world > 1:
+            dist.all_gather(gathered, tokens)          # the path's only exchange: token ids over xGMI (RCCL)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_gen = n_tok.cpu().numpy()
+    prof = {k: ctx.profile_read(k) for k in ("logmel", "enc_gemm", "crosskv_gemm", "enc_attention", "enc_norm", "decode")}
+    ms_per_step = elapsed / args.steps * 1e3
+    audio_s = 30.0 * B * world
+    value = audio_s * args.steps / elapsed
+
+    # roofline of the dominant kernel class (largest share of the timed region on this rank)
+    n_l, ms_l, w_l = prof["enc_gemm"]
+    gemm_tflops = (w_l / n_l) / ((ms_l / n_l) * 1e-3) / 1e12 if n_l else 0.0
+    n_d, ms_d, steps_d = prof["decode"]
+    L, D, V, T = dims.n_text_layer, dims.n_text_state, dims.n_vocab, dims.n_audio_ctx
+    dec_bytes_per_step = 2.0 * (L * (10 * D * D + 8 * D * D) + V * D) + B * L * 2 * T * D * 2.0   # weights once + cross-KV of B clips
+    dec_gbs = dec_bytes_per_step * steps_d / (ms_d * 1e-3) / 1e9 if ms_d else 0.0
+    shares = {k: v[1] / (elapsed * 1e3) for k, v in prof.items()}
+    if shares["enc_gemm"] >= shares["decode"]:
+        roofline = {"kernel": "gemm_nt_kernel (encoder Linear/Conv GEMMs, 128x128x64 MFMA tiles)", "bound": "mfma",
+                    "achieved": round(gemm_tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(gemm_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": n_l, "avg_launch_ms": round(ms_l / max(n_l, 1), 4), "flop_per_launch_avg": w_l / max(n_l, 1)}
+    else:
+        roofline = {"kernel": "decode step graph (skinny MFMA GEMMs + KV-cache attention + decode head)", "bound": "hbm",
+                    "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
+                    "traffic": None, "launches": int(steps_d), "avg_launch_ms": round(ms_d / max(steps_d, 1), 4),
+                    "bytes_per_launch": dec_bytes_per_step}
+    stage = {k: {"ms_per_step": round(v[1] / args.steps, 3), "share": round(shares[k], 4)} for k, v in prof.items()}
+    stage["enc_gemm"]["tflops"] = round(gemm_tflops, 1)
+    if prof["enc_attention"][0]:
+        stage["enc_attention"]["tflops"] = round(prof["enc_attention"][2] / (prof["enc_attention"][1] * 1e-3) / 1e12, 1)
+    if prof["logmel"][0]:
+        stage["logmel"]["GBs_algorithmic"] = round(prof["logmel"][2] / (prof["logmel"][1] * 1e-3) / 1e9, 1)
+    stage["decode"]["GBs_algorithmic"] = round(dec_gbs, 1)
+    stage["decode"]["steps_per_pass"] = steps_d / max(n_d, 1)
+
+    out = {
+        "metric": "audio-sec/s (Whisper large-v3-turbo b=32) at 1/2/4/8 GPU; codec samples/s",
+        "value": round(value, 2), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"Whisper {args.model} {args.dtype}, batch={B}x30 s synthetic clips per MI355X, log-mel+encode+greedy decode "
+                               f"(T=0, timestamps, max_tokens 448, one window per clip), random-init N(0,0.02^2) weights",
+                   "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "generated_tokens_per_clip_mean": float(n_gen.mean()), "decoder_steps_per_pass": steps_d / max(n_d, 1),
+                   "realtime_factor": round(value, 1)},
+        "roofline": roofline, "stages": stage,
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            ncpu = min(16, len(os.sched_getaffinity(0)))   # the GPU box's CPU share for one GPU is 16 cores
+            out["cpu_baseline"] = cpu_baseline(args.model, args.seed, ncpu, args.cpu_tokens)
+        except Exception as e:  # the CPU leg must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "unit": "audio-sec/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    model.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,14 @@ void* mia_stream(mia_ctx* ctx);
 /* Block until everything enqueued on the ctx stream has finished. */
 int mia_synchronize(mia_ctx* ctx);
 
+/* ---- profiling ------------------------------------------------------------------------------ */
+/* Optional HIP-event timing of kernel classes on the ctx stream (events bracket each launch of the class).
+ * Classes: "logmel" (work = algorithmic bytes), "enc_gemm", "crosskv_gemm", "enc_attention" (work = FLOPs),
+ * "enc_norm" (bytes), "decode" (work = decoder steps).  Reading synchronises the stream. */
+int mia_profile_enable(mia_ctx* ctx, int on);
+int mia_profile_reset(mia_ctx* ctx);
+int mia_profile_read(mia_ctx* ctx, const char* kernel_class, int64_t* launches, double* total_ms, double* total_work);
+
 /* ---- DSP front end -------------------------------------------------------------------------- */
 /* Whisper log-mel.  Replaces whisperLogMelSpectrogram(audio:nMels:padding:)
  * (STT/Whisper/WhisperAudio.swift:78-137, called at STT/Whisper/WhisperSTT.swift:140-145) and the

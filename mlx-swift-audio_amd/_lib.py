@@ -65,6 +65,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.mia_stream.argtypes = [vp]
     lib.mia_synchronize.restype = i32
     lib.mia_synchronize.argtypes = [vp]
+    lib.mia_profile_enable.restype = i32
+    lib.mia_profile_enable.argtypes = [vp, i32]
+    lib.mia_profile_reset.restype = i32
+    lib.mia_profile_reset.argtypes = [vp]
+    lib.mia_profile_read.restype = i32
+    lib.mia_profile_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     for name in ("mia_logmel_whisper", "mia_logmel_s3"):
         f = getattr(lib, name)
         f.restype = i32
@@ -87,6 +93,18 @@ class Context:
     def check(self, rc: int) -> None:
         if rc != MIA_OK:
             raise MiaError(rc, self.lib.mia_last_error(self.h).decode())
+
+    def profile(self, on: bool) -> None:
+        self.check(self.lib.mia_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self) -> None:
+        self.check(self.lib.mia_profile_reset(self.h))
+
+    def profile_read(self, kernel_class: str) -> tuple[int, float, float]:
+        """(launches, total milliseconds, total work) of a kernel class since the last reset."""
+        n, ms, work = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+        self.check(self.lib.mia_profile_read(self.h, kernel_class.encode(), C.byref(n), C.byref(ms), C.byref(work)))
+        return n.value, ms.value, work.value
 
     def synchronize(self) -> None:
         self.check(self.lib.mia_synchronize(self.h))

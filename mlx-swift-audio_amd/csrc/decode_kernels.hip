@@ -12,53 +12,105 @@
 #include "decode.h"
 
 // ------------------------------------------------------------------------------------------------
-// x[b] = E[token[b][pos]] + P[pos];  h[b] = LN(x[b])          (TextDecoder.swift:67 + first attn_ln)
+// Row kernels of the decode step: one 256-thread workgroup per clip, the row (D <= 2048 floats) lives in
+// registers as float4, statistics via wave shuffles + one LDS hop.
 // ------------------------------------------------------------------------------------------------
+constexpr int ROW_NV = 2;   // float4 per thread: D <= 256 * 4 * ROW_NV
+
+__device__ __forceinline__ float block256_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void dec_embed_ln(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ emb,
-                                                   const float* __restrict__ pos_emb, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, float* __restrict__ x,
-                                                   uint16_t* __restrict__ h, const DecState* __restrict__ st, int D, int n_ctx) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void row_layernorm_store(const f32x4 (&v)[ROW_NV], int nv, int D, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, uint16_t* __restrict__ hrow, float* sh) {
+  const int tid = threadIdx.x;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) if (tid + 256 * i < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = block256_sum(s, sh) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i)
+    if (tid + 256 * i < nv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    }
+  const float rstd = rsqrtf(block256_sum(q, sh) / (float)D + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int c = tid + 256 * i;
+    if (c >= nv) continue;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 4 * c);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bt[j];
+    *reinterpret_cast<u32x2*>(hrow + 4 * c) = (u32x2){pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+  }
+}
+
+// x[b] = E[token[b][pos]] + P[pos];  h[b] = LN(x[b])          (TextDecoder.swift:67 + first attn_ln)
+template <typename T>
+__global__ __launch_bounds__(256) void dec_embed_ln(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ emb,
+                                                    const float* __restrict__ pos_emb, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ x,
+                                                    uint16_t* __restrict__ h, const DecState* __restrict__ st, int D, int n_ctx) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int pos = st->pos;
   const int tok = tokens[b * n_ctx + pos];
   const uint16_t* e = emb + (int64_t)tok * D;
   const float* p = pos_emb + (int64_t)pos * D;
   float* xr = x + (int64_t)b * D;
-  float s = 0.f;
-  for (int i = lane; i < D; i += 64) {
-    const float v = T::to_f32(e[i]) + p[i];
-    xr[i] = v;
-    s += v;
+  const int nv = D >> 2;
+  f32x4 v[ROW_NV];
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nv) {
+      const s16x4 ev = *reinterpret_cast<const s16x4*>(e + 4 * c);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(p + 4 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = T::to_f32((uint16_t)ev[j]) + pv[j];
+      *reinterpret_cast<f32x4*>(xr + 4 * c) = v[i];
+    } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-  for (int i = lane; i < D; i += 64) { const float d = xr[i] - mean; q += d * d; }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
-  for (int i = lane; i < D; i += 64) h[(int64_t)b * D + i] = T::from_f32((xr[i] - mean) * rstd * gamma[i] + beta[i]);
+  row_layernorm_store<T>(v, nv, D, gamma, beta, h + (int64_t)b * D, sh);
 }
 
-// ------------------------------------------------------------------------------------------------
 // x[b] += bias + sum_s partial[s][b];  h[b] = LN(x[b])        (residual add + next LayerNorm, fixed-order split-K sum)
-// ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void dec_reduce_ln(const float* __restrict__ partial, int S, int B, const float* __restrict__ bias,
-                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    float* __restrict__ x, uint16_t* __restrict__ h, int D) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void dec_reduce_ln(const float* __restrict__ partial, int S, int B, const float* __restrict__ bias,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ x, uint16_t* __restrict__ h, int D) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
   float* xr = x + (int64_t)b * D;
-  float s = 0.f;
-  for (int i = lane; i < D; i += 64) {
-    float v = xr[i] + bias[i];
-    for (int k = 0; k < S; ++k) v += partial[((int64_t)k * B + b) * D + i];
-    xr[i] = v;
-    s += v;
+  const int nv = D >> 2;
+  f32x4 v[ROW_NV];
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nv) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+      const f32x4 bs = *reinterpret_cast<const f32x4*>(bias + 4 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += bs[j];
+      for (int k = 0; k < S; ++k) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(partial + ((int64_t)k * B + b) * D + 4 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] += pv[j];
+      }
+      v[i] = a;
+      *reinterpret_cast<f32x4*>(xr + 4 * c) = a;
+    } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-  for (int i = lane; i < D; i += 64) { const float d = xr[i] - mean; q += d * d; }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
-  for (int i = lane; i < D; i += 64) h[(int64_t)b * D + i] = T::from_f32((xr[i] - mean) * rstd * gamma[i] + beta[i]);
+  row_layernorm_store<T>(v, nv, D, gamma, beta, h + (int64_t)b * D, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -82,21 +134,44 @@ __global__ __launch_bounds__(64) void dec_skinny_gemm(SkinnyArgs a) {
   const uint16_t* ap0 = a.A + (int64_t)am0 * a.lda + kbeg + 8 * c;
   const uint16_t* ap1 = a.A + (int64_t)am1 * a.lda + kbeg + 8 * c;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  // 4 K-steps (128 k) per iteration: 12 independent 16-byte loads in flight before the first MFMA
+  // Software-pipelined register double buffer: batch i+1 (4 K-steps = 12 independent 16-byte loads per lane) is
+  // issued before the MFMAs of batch i, so ~24 loads per lane stay in flight (weights are HBM-once traffic).
+  struct Batch { s16x8 w[4], a0[4], a1[4]; };
+  auto load_batch = [&](Batch& t, int k) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      t.w[u] = *reinterpret_cast<const s16x8*>(wp + k + 32 * u);
+      t.a0[u] = *reinterpret_cast<const s16x8*>(ap0 + k + 32 * u);
+      t.a1[u] = *reinterpret_cast<const s16x8*>(ap1 + k + 32 * u);
+    }
+  };
+  auto mma_batch = [&](const Batch& t) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = T::mfma16(t.w[u], t.a0[u], acc0);
+      acc1 = T::mfma16(t.w[u], t.a1[u], acc1);
+    }
+  };
+  const int nb = Kc / 128;
   int k = 0;
-  for (; k + 128 <= Kc; k += 128) {
-    s16x8 fw[4], fa0[4], fa1[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      fw[u] = *reinterpret_cast<const s16x8*>(wp + k + 32 * u);
-      fa0[u] = *reinterpret_cast<const s16x8*>(ap0 + k + 32 * u);
-      fa1[u] = *reinterpret_cast<const s16x8*>(ap1 + k + 32 * u);
+  if (nb > 0) {
+    Batch b0, b1;
+    load_batch(b0, 0);
+    int i = 0;
+    for (; i + 2 <= nb - 1; i += 2) {      // two batches per trip so both buffers keep static register names
+      load_batch(b1, (i + 1) * 128);
+      mma_batch(b0);
+      load_batch(b0, (i + 2) * 128);
+      mma_batch(b1);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc0 = T::mfma16(fw[u], fa0[u], acc0);
-      acc1 = T::mfma16(fw[u], fa1[u], acc1);
+    if (i + 1 <= nb - 1) {
+      load_batch(b1, (i + 1) * 128);
+      mma_batch(b0);
+      mma_batch(b1);
+    } else {
+      mma_batch(b0);
     }
+    k = nb * 128;
   }
   for (; k < Kc; k += 32) {
     const s16x8 fw = *reinterpret_cast<const s16x8*>(wp + k);
@@ -165,19 +240,25 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = T::to_f32((uint16_t)qv[j]);
   }
-  // ---- scores
-  for (int k0 = wave * 8; k0 < nk; k0 += 32) {
-    const int key = k0 + g;
-    float dot = 0.f;
-    if (key < nk) {
-      const s16x8 kv = *reinterpret_cast<const s16x8*>(kb + (int64_t)key * 64 + c * 8);
+  // ---- scores: each wave owns 32 consecutive keys per trip (4 independent 1 KB loads in flight)
+  for (int k0 = wave * 32; k0 < nk; k0 += 128) {
+    s16x8 kv[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dot += qf[j] * T::to_f32((uint16_t)kv[j]);
+    for (int u = 0; u < 4; ++u) {
+      int key = k0 + 8 * u + g; key = key < nk ? key : nk - 1;
+      kv[u] = *reinterpret_cast<const s16x8*>(kb + (int64_t)key * 64 + c * 8);
     }
-    dot += __shfl_xor(dot, 1, 64);
-    dot += __shfl_xor(dot, 2, 64);
-    dot += __shfl_xor(dot, 4, 64);
-    if (c == 0 && key < nk) sc[key] = dot * scale;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot += qf[j] * T::to_f32((uint16_t)kv[u][j]);
+      dot += __shfl_xor(dot, 1, 64);
+      dot += __shfl_xor(dot, 2, 64);
+      dot += __shfl_xor(dot, 4, 64);
+      const int key = k0 + 8 * u + g;
+      if (c == 0 && key < nk) sc[key] = dot * scale;
+    }
   }
   __syncthreads();
   // ---- softmax over sc[0..nk)
@@ -197,14 +278,20 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int k0 = wave * 8; k0 < nk; k0 += 32) {
-    const int key = k0 + g;
-    if (key < nk) {
-      const float p = sc[key];
-      const s16x8 vv = *reinterpret_cast<const s16x8*>(vb + (int64_t)key * 64 + c * 8);
+  for (int k0 = wave * 32; k0 < nk; k0 += 128) {
+    s16x8 vv[4];
+    float pw[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += p * T::to_f32((uint16_t)vv[j]);
+    for (int u = 0; u < 4; ++u) {
+      const int key = k0 + 8 * u + g;
+      const int kc2 = key < nk ? key : nk - 1;
+      vv[u] = *reinterpret_cast<const s16x8*>(vb + (int64_t)kc2 * 64 + c * 8);
+      pw[u] = key < nk ? sc[kc2] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += pw[u] * T::to_f32((uint16_t)vv[u][j]);
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -240,58 +327,47 @@ struct HeadBufs {
   const DecState* st;
 };
 
-__device__ __forceinline__ float block_max(float v, float* sh) {
-  v = wave_max(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = sh[0];
-  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, sh[i]);
-  return r;
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax amax(ArgMax a, ArgMax b) {   // larger value wins, lowest index wins ties (MLX argMax)
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
-__device__ __forceinline__ float block_sum(float v, float* sh) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = 0.f;
-  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
-  return r;
+__device__ __forceinline__ ArgMax wave_amax(ArgMax a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgMax b{__shfl_xor(a.v, o, 64), __shfl_xor(a.i, o, 64)};
+    a = amax(a, b);
+  }
+  return a;
 }
 
+// Two passes over the clip's logits (L2 resident): pass 1 = every max / argmax, pass 2 = every exp-sum.
+// The timestamp heuristic (:299-322) decides between two precomputed candidates: A = rules only, B = rules + "text
+// suppressed".  log-sum-exps use the max-shifted form; ts_lse = (max_ts - lse) + log(sum_ts exp(x - max_ts)).
 __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
-  __shared__ float sh[16];
-  __shared__ int shi[16];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float shf[16][4];
+  __shared__ float sha[16][2];
+  __shared__ int shai[16][2];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = p.V;
   const float* lg = hb.logits + (int64_t)b * V;
   const int pos = hb.st->pos;
   const int cur_len = pos + 1;
   int32_t* toks = hb.tokens + (int64_t)b * p.n_ctx;
-
-  // raw log-sum-exp of the logits (used by the no-speech probe and the timestamp heuristic)
-  float mx = -INFINITY;
-  for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, lg[i]);
-  mx = block_max(mx, sh);
-  float se = 0.f;
-  for (int i = tid; i < V; i += 1024) se += __expf(lg[i] - mx);
-  se = block_sum(se, sh);
-  const float lse = mx + __logf(se);
-
-  if (pos == p.sot_index && tid == 0) hb.no_speech[b] = __expf(lg[p.no_speech] - lse);   // softmax(logits[sot])[no_speech]
-  if (cur_len < p.n_initial) return;                  // next token is forced by the initial sequence
-  if (hb.finished[b]) {
+  const bool generating = cur_len >= p.n_initial;
+  if (!generating && pos != p.sot_index) return;      // forced token and no probe wanted: nothing to do
+  if (generating && hb.finished[b]) {
     if (tid == 0 && cur_len < p.n_ctx) toks[cur_len] = p.eot;
-    return;
+    if (pos != p.sot_index) return;
   }
+  const bool decide = generating && !hb.finished[b];
   const int num_gen = cur_len - p.n_initial;          // == loop iteration of the reference
   const int tsb = p.timestamp_begin;
 
   // ---- rule state (WhisperDecoding.swift:221-292)
-  bool sup_ts_all = false, sup_text_below_eot = false, sup_below_tsb = false;
+  bool sup_ts_all = false, sup_text_below_eot = false, sup_below_tsb = false, heuristic = false;
   int ts_floor = 0;                                   // suppress tsb <= idx < ts_floor
   int max_first = V;                                  // suppress idx > max_first (first token only)
-  if (p.timestamps) {
+  if (decide && p.timestamps) {
     const int last = toks[cur_len - 1];
     const bool last_was_ts = num_gen >= 1 && last >= tsb;
     const bool penult_was_ts = num_gen < 2 || toks[cur_len - 2] >= tsb;
@@ -303,25 +379,11 @@ __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
       const int last_allowed = tsb + p.max_initial_ts;
       if (last_allowed < V) max_first = last_allowed;
     }
-    if (num_gen > 0) {
-      // heuristic on RAW logits (:299-322): logsumexp of timestamp log-probs vs max text log-prob
-      float tmax = -INFINITY, xmax = -INFINITY;
-      for (int i = tid; i < V; i += 1024) {
-        const float lp = lg[i] - lse;
-        if (i >= tsb) tmax = fmaxf(tmax, lp); else xmax = fmaxf(xmax, lp);
-      }
-      tmax = block_max(tmax, sh);
-      xmax = block_max(xmax, sh);
-      float ts = 0.f;
-      for (int i = tsb + tid; i < V; i += 1024) ts += __expf((lg[i] - lse) - tmax);
-      ts = block_sum(ts, sh);
-      const float ts_lse = tmax + __logf(ts);
-      if (ts_lse > xmax) sup_below_tsb = true;
-    }
+    heuristic = num_gen > 0;
   }
   const int nw = (V + 31) / 32;
   const uint32_t* bits = hb.suppress + (num_gen == 0 ? nw : 0);
-  auto masked = [&](int i) -> bool {
+  auto maskedA = [&](int i) -> bool {
     if ((bits[i >> 5] >> (i & 31)) & 1u) return true;
     if (p.timestamps) {
       if (i == p.no_timestamps) return true;
@@ -333,42 +395,84 @@ __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
     }
     return false;
   };
-  // ---- argmax over the filtered logits (lowest index wins ties) + their log-sum-exp
-  float best = -INFINITY; int besti = 0x7fffffff;
-  float fmx = -INFINITY;
-  for (int i = tid; i < V; i += 1024) {
-    if (masked(i)) continue;
-    const float v = lg[i];
-    if (v > best || (v == best && i < besti)) { best = v; besti = i; }
-  }
-  fmx = block_max(best, sh);
-  // index of the max: smallest index among threads holding the max value
-  int cand = (best == fmx) ? besti : 0x7fffffff;
-  for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
-  __syncthreads();
-  if ((tid & 63) == 0) shi[tid >> 6] = cand;
-  __syncthreads();
-  int next = shi[0];
-  for (int i = 1; i < 16; ++i) next = min(next, shi[i]);
-  // Everything masked: reachable in the reference when the raw-logit timestamp heuristic (:299-322) fires right
-  // after a timestamp pair rule; MLX argMax of an all -inf vector is index 0 and log(softmax) is NaN. Mirror that.
-  const bool all_masked = next == 0x7fffffff;
-  if (all_masked) next = 0;
-  float fse = 0.f;
-  for (int i = tid; i < V; i += 1024) if (!masked(i)) fse += __expf(lg[i] - fmx);
-  fse = block_sum(fse, sh);
-  if (tid == 0) {
-    if (next != p.eot) {                              // EOT excluded from avg_logprob (:345-350)
-      hb.sum_logprob[b] += all_masked ? __int_as_float(0x7fc00000) : (lg[next] - fmx) - __logf(fse);
-      hb.n_logprob[b] += 1;
+
+  // ---- pass 1: maxima
+  float mx_text = -INFINITY, mx_ts = -INFINITY;
+  ArgMax bA{-INFINITY, 0x7fffffff}, bB{-INFINITY, 0x7fffffff};
+  for (int i0 = tid; i0 < V; i0 += 4096) {
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + 1024 * u; x[u] = i < V ? lg[i] : -INFINITY; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 1024 * u;
+      if (i >= V) continue;
+      if (i >= tsb) mx_ts = fmaxf(mx_ts, x[u]); else mx_text = fmaxf(mx_text, x[u]);
+      if (decide && !maskedA(i)) {
+        bA = amax(bA, ArgMax{x[u], i});
+        if (i >= tsb) bB = amax(bB, ArgMax{x[u], i});
+      }
     }
-    toks[cur_len] = next;
-    hb.n_gen[b] = num_gen + 1;
-    if (next > tsb) hb.last_ts[b] = next;             // strict '>' (:254-256)
-    int cap = p.max_tokens - p.n_initial;
-    if (p.max_new_tokens > 0 && p.max_new_tokens < cap) cap = p.max_new_tokens;
-    if (next == p.eot || num_gen + 1 >= cap) hb.finished[b] = 1;
   }
+  mx_text = wave_max(mx_text); mx_ts = wave_max(mx_ts);
+  bA = wave_amax(bA); bB = wave_amax(bB);
+  if (lane == 0) { shf[wave][0] = mx_text; shf[wave][1] = mx_ts; sha[wave][0] = bA.v; shai[wave][0] = bA.i; sha[wave][1] = bB.v; shai[wave][1] = bB.i; }
+  __syncthreads();
+  mx_text = shf[0][0]; mx_ts = shf[0][1]; bA = ArgMax{sha[0][0], shai[0][0]}; bB = ArgMax{sha[0][1], shai[0][1]};
+  for (int w2 = 1; w2 < 16; ++w2) {
+    mx_text = fmaxf(mx_text, shf[w2][0]); mx_ts = fmaxf(mx_ts, shf[w2][1]);
+    bA = amax(bA, ArgMax{sha[w2][0], shai[w2][0]}); bB = amax(bB, ArgMax{sha[w2][1], shai[w2][1]});
+  }
+  const float mx_all = fmaxf(mx_text, mx_ts);
+  __syncthreads();
+
+  // ---- pass 2: exp-sums
+  float s_all = 0.f, s_ts = 0.f, fA = 0.f, fB = 0.f;
+  for (int i0 = tid; i0 < V; i0 += 4096) {
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + 1024 * u; x[u] = i < V ? lg[i] : -INFINITY; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 1024 * u;
+      if (i >= V) continue;
+      s_all += __expf(x[u] - mx_all);
+      if (heuristic && i >= tsb) s_ts += __expf(x[u] - mx_ts);
+      if (decide && !maskedA(i)) {
+        fA += __expf(x[u] - bA.v);
+        if (heuristic && i >= tsb) fB += __expf(x[u] - bB.v);
+      }
+    }
+  }
+  s_all = wave_sum(s_all); s_ts = wave_sum(s_ts); fA = wave_sum(fA); fB = wave_sum(fB);
+  if (lane == 0) { shf[wave][0] = s_all; shf[wave][1] = s_ts; shf[wave][2] = fA; shf[wave][3] = fB; }
+  __syncthreads();
+  if (tid != 0) return;
+  s_all = s_ts = fA = fB = 0.f;
+  for (int w2 = 0; w2 < 16; ++w2) { s_all += shf[w2][0]; s_ts += shf[w2][1]; fA += shf[w2][2]; fB += shf[w2][3]; }
+  const float lse = mx_all + __logf(s_all);
+  if (pos == p.sot_index) hb.no_speech[b] = __expf(lg[p.no_speech] - lse);   // softmax(logits[sot])[no_speech] (:158-169)
+  if (!decide) return;
+  ArgMax best = bA; float fsum = fA;
+  if (heuristic) {
+    const float ts_lse = (mx_ts - lse) + __logf(s_ts);
+    const float max_text = mx_text - lse;
+    if (ts_lse > max_text) { best = bB; fsum = fB; }   // force a timestamp: text tokens suppressed too
+  }
+  // Everything masked: reachable in the reference when the raw-logit timestamp heuristic fires right after a
+  // timestamp pair rule; MLX argMax of an all -inf vector is index 0 and log(softmax) is NaN.  Mirror that.
+  const bool all_masked = best.i == 0x7fffffff;
+  const int next = all_masked ? 0 : best.i;
+  if (next != p.eot) {                                // EOT excluded from avg_logprob (:345-350)
+    hb.sum_logprob[b] += all_masked ? __int_as_float(0x7fc00000) : -__logf(fsum);
+    hb.n_logprob[b] += 1;
+  }
+  toks[cur_len] = next;
+  hb.n_gen[b] = num_gen + 1;
+  if (next > tsb) hb.last_ts[b] = next;               // strict '>' (:254-256)
+  int cap = p.max_tokens - p.n_initial;
+  if (p.max_new_tokens > 0 && p.max_new_tokens < cap) cap = p.max_new_tokens;
+  if (next == p.eot || num_gen + 1 >= cap) hb.finished[b] = 1;
 }
 
 __global__ void dec_advance(DecState* st) { st->pos += 1; }
@@ -397,18 +501,18 @@ __global__ void dec_finalize(const int32_t* __restrict__ tokens, const int32_t* 
 int dec_launch_embed_ln(mia_whisper* w, const LNW& ln, hipStream_t s) {
   const int D = w->dims.n_text_state;
   if (w->dtype == MIA_F16)
-    hipLaunchKernelGGL(dec_embed_ln<F16>, dim3(w->cur_B), dim3(64), 0, s, w->tokens, (const uint16_t*)w->tok_emb, w->dec_pos, ln.g, ln.b, w->dx, (uint16_t*)w->dh, w->state, D, w->dims.n_text_ctx);
+    hipLaunchKernelGGL(dec_embed_ln<F16>, dim3(w->cur_B), dim3(256), 0, s, w->tokens, (const uint16_t*)w->tok_emb, w->dec_pos, ln.g, ln.b, w->dx, (uint16_t*)w->dh, w->state, D, w->dims.n_text_ctx);
   else
-    hipLaunchKernelGGL(dec_embed_ln<BF16>, dim3(w->cur_B), dim3(64), 0, s, w->tokens, (const uint16_t*)w->tok_emb, w->dec_pos, ln.g, ln.b, w->dx, (uint16_t*)w->dh, w->state, D, w->dims.n_text_ctx);
+    hipLaunchKernelGGL(dec_embed_ln<BF16>, dim3(w->cur_B), dim3(256), 0, s, w->tokens, (const uint16_t*)w->tok_emb, w->dec_pos, ln.g, ln.b, w->dx, (uint16_t*)w->dh, w->state, D, w->dims.n_text_ctx);
   return 0;
 }
 
 int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln, hipStream_t s) {
   const int D = w->dims.n_text_state;
   if (w->dtype == MIA_F16)
-    hipLaunchKernelGGL(dec_reduce_ln<F16>, dim3(w->cur_B), dim3(64), 0, s, w->partial, S, w->cur_B, bias, ln.g, ln.b, w->dx, (uint16_t*)w->dh, D);
+    hipLaunchKernelGGL(dec_reduce_ln<F16>, dim3(w->cur_B), dim3(256), 0, s, w->partial, S, w->cur_B, bias, ln.g, ln.b, w->dx, (uint16_t*)w->dh, D);
   else
-    hipLaunchKernelGGL(dec_reduce_ln<BF16>, dim3(w->cur_B), dim3(64), 0, s, w->partial, S, w->cur_B, bias, ln.g, ln.b, w->dx, (uint16_t*)w->dh, D);
+    hipLaunchKernelGGL(dec_reduce_ln<BF16>, dim3(w->cur_B), dim3(256), 0, s, w->partial, S, w->cur_B, bias, ln.g, ln.b, w->dx, (uint16_t*)w->dh, D);
   return 0;
 }
 

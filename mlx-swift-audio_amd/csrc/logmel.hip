@@ -293,6 +293,9 @@ int mia_logmel_device(mia_ctx* ctx, const float* pcm_dev, const int64_t* offs_ho
   float* d_tmp = (float*)s;
 
   MIA_HIP(ctx, hipMemcpyAsync(d_clips, clips.data(), (size_t)B * sizeof(ClipInfo), hipMemcpyHostToDevice, ctx->stream));
+  double alg_bytes = 0.0;   // algorithmic traffic: audio read once + output written once
+  for (int b = 0; b < B; ++b) alg_bytes += (double)clips[b].len * 4.0 + (double)n_out * n_mels * mia_dtype_size(out_dtype);
+  const int prof_rec = mia_prof_begin(ctx, MIA_PROF_LOGMEL, alg_bytes);
   hipLaunchKernelGGL(logmel_init, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, d_gmax, B);
   if (max_content > 0) {
     static bool lds_attr_set = false;   // 86 KB of dynamic LDS: above the 64 KB default cap
@@ -320,6 +323,7 @@ int mia_logmel_device(mia_ctx* ctx, const float* pcm_dev, const int64_t* offs_ho
     else LAUNCH2(BF16, false);
   }
 #undef LAUNCH2
+  mia_prof_end(ctx, prof_rec);
   MIA_HIP(ctx, hipGetLastError());
   // clips[] lives on the host stack of this call: the async H2D copy above must have consumed it.
   MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));

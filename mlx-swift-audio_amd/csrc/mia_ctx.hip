@@ -46,6 +46,8 @@ extern "C" void mia_destroy(mia_ctx* ctx) {
     (void)hipFree(t.fb_w);
     (void)hipFree(t.fb_meta);
   }
+  for (auto& r : ctx->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -75,4 +77,61 @@ void* mia_workspace(mia_ctx* ctx, size_t bytes) {
   }
   ctx->ws_bytes = want;
   return ctx->ws;
+}
+
+// ---- profiling -------------------------------------------------------------------------------
+static hipEvent_t get_event(mia_ctx* ctx) {
+  if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+int mia_prof_begin(mia_ctx* ctx, int cls, double work) {
+  if (!ctx->prof_on) return -1;
+  mia_ctx::ProfRec r{cls, get_event(ctx), get_event(ctx), work};
+  if (!r.start || !r.stop) return -1;
+  (void)hipEventRecord(r.start, ctx->stream);
+  ctx->prof.push_back(r);
+  return (int)ctx->prof.size() - 1;
+}
+
+void mia_prof_end(mia_ctx* ctx, int rec) {
+  if (rec < 0) return;
+  (void)hipEventRecord(ctx->prof[rec].stop, ctx->stream);
+}
+
+static const char* kProfNames[MIA_PROF_NCLASSES] = {"logmel", "enc_gemm", "enc_attention", "enc_norm", "decode", "crosskv_gemm"};
+
+extern "C" int mia_profile_enable(mia_ctx* ctx, int on) {
+  if (!ctx) return MIA_ERR_INVALID_ARGUMENT;
+  ctx->prof_on = on != 0;
+  return MIA_OK;
+}
+
+extern "C" int mia_profile_reset(mia_ctx* ctx) {
+  if (!ctx) return MIA_ERR_INVALID_ARGUMENT;
+  MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->prof) { ctx->ev_pool.push_back(r.start); ctx->ev_pool.push_back(r.stop); }
+  ctx->prof.clear();
+  return MIA_OK;
+}
+
+extern "C" int mia_profile_read(mia_ctx* ctx, const char* kernel_class, int64_t* launches, double* total_ms, double* total_work) {
+  if (!ctx || !kernel_class) return MIA_ERR_INVALID_ARGUMENT;
+  int cls = -1;
+  for (int i = 0; i < MIA_PROF_NCLASSES; ++i) if (!strcmp(kProfNames[i], kernel_class)) cls = i;
+  MIA_CHECK_ARG(ctx, cls >= 0, "profile_read: unknown kernel class '%s'", kernel_class);
+  MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t n = 0; double ms = 0.0, work = 0.0;
+  for (auto& r : ctx->prof) {
+    if (r.cls != cls) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) continue;
+    ++n; ms += t; work += r.work;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (total_work) *total_work = work;
+  return MIA_OK;
 }

@@ -29,7 +29,19 @@ struct mia_ctx {
     int fb_nnz = 0;
   };
   std::vector<MelTables> mel_tables;
+  // optional HIP-event profiling of kernel classes (mia_profile_*): bench.py's roofline figures come from here
+  bool prof_on = false;
+  struct ProfRec { int cls; hipEvent_t start, stop; double work; };
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
 };
+
+enum { MIA_PROF_LOGMEL = 0, MIA_PROF_ENC_GEMM = 1, MIA_PROF_ENC_ATTN = 2, MIA_PROF_ENC_NORM = 3, MIA_PROF_DECODE = 4,
+       MIA_PROF_CROSSKV_GEMM = 5, MIA_PROF_NCLASSES = 6 };
+
+// RAII-less helpers: if profiling is on, bracket the launches between begin/end with events on the ctx stream
+int mia_prof_begin(mia_ctx* ctx, int cls, double work);   // returns record index or -1
+void mia_prof_end(mia_ctx* ctx, int rec);
 
 inline int mia_fail(mia_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];

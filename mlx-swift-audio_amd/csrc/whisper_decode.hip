@@ -136,7 +136,10 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
   if (p.max_new_tokens > 0 && p.max_new_tokens < cap) cap = p.max_new_tokens;
   const int total_steps = p.n_initial + cap - 1;
   std::vector<int32_t> fin(B);
+  int prof_rec = mia_prof_begin(ctx, MIA_PROF_DECODE, 0.0);
+  int steps_run = 0;
   for (int step = 0; step < total_steps; ++step) {
+    ++steps_run;
     if (no_graph) { if (enqueue_step(w, p) != 0) return mia_fail(ctx, MIA_ERR_DEVICE, "decode: step launch failed"); }
     else MIA_HIP(ctx, hipGraphLaunch(w->step_graph, s));
     // early exit: poll the finished flags every 16 steps once generation has started
@@ -148,6 +151,7 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
       if (all) break;
     }
   }
+  if (prof_rec >= 0) { ctx->prof[prof_rec].work = steps_run; mia_prof_end(ctx, prof_rec); }
   dec_launch_finalize(w, w->out_n, p, s);
   MIA_HIP(ctx, hipGetLastError());
   const hipMemcpyKind kind = mem == MIA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;

@@ -8,9 +8,20 @@
 
 namespace {
 
-int gemm(mia_whisper* w, const GemmArgs& g) {
+int gemm(mia_whisper* w, const GemmArgs& g, int cls = MIA_PROF_ENC_GEMM) {
   if (const char* e = mia_gemm_check(g)) return mia_fail(w->ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
-  if (mia_gemm_launch(g, w->dtype, w->ctx->stream) != 0) return mia_fail(w->ctx, MIA_ERR_DEVICE, "gemm launch failed");
+  const int rec = mia_prof_begin(w->ctx, cls, 2.0 * g.M * (double)g.N * g.K * (g.batch > 0 ? g.batch : 1));
+  const int rc = mia_gemm_launch(g, w->dtype, w->ctx->stream);
+  mia_prof_end(w->ctx, rec);
+  if (rc != 0) return mia_fail(w->ctx, MIA_ERR_DEVICE, "gemm launch failed");
+  return MIA_OK;
+}
+
+int norm(mia_whisper* w, const LNW& ln, void* out, int M, int D) {
+  const int rec = mia_prof_begin(w->ctx, MIA_PROF_ENC_NORM, (double)M * D * 6.0);   // fp32 in + 16-bit out
+  const int rc = mia_norm_launch(w->x, D, ln.g, ln.b, out, D, M, D, 1e-5f, false, w->dtype, w->ctx->stream);
+  mia_prof_end(w->ctx, rec);
+  if (rc) return mia_fail(w->ctx, MIA_ERR_DEVICE, "norm launch failed");
   return MIA_OK;
 }
 
@@ -102,7 +113,7 @@ int whisper_encode_from_padded_mel(mia_whisper* w, int B) {
   }
   for (int l = 0; l < d.n_audio_layer; ++l) {
     const EncBlockW& b = w->enc[l];
-    if (mia_norm_launch(w->x, D, b.attn_ln.g, b.attn_ln.b, w->h, D, M, D, 1e-5f, false, w->dtype, s)) return mia_fail(w->ctx, MIA_ERR_DEVICE, "norm launch failed");
+    if ((rc = norm(w, b.attn_ln, w->h, M, D)) != MIA_OK) return rc;
     {
       GemmArgs g;
       g.A = w->h; g.lda = D; g.W = b.qkv.w; g.bias = b.qkv.b;
@@ -111,7 +122,12 @@ int whisper_encode_from_padded_mel(mia_whisper* w, int B) {
       if ((rc = gemm(w, g)) != MIA_OK) return rc;
     }
     if (const char* e = mia_enc_attention_check(B, T, H, w->Tpad, 2 * D, D)) return mia_fail(w->ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
-    if (mia_enc_attention_launch(w->qk, 2 * D, w->vt, w->att, D, B, T, H, w->Tpad, w->dtype, s)) return mia_fail(w->ctx, MIA_ERR_DEVICE, "attention launch failed");
+    {
+      const int rec = mia_prof_begin(w->ctx, MIA_PROF_ENC_ATTN, 4.0 * B * H * (double)T * T * 64);
+      const int arc = mia_enc_attention_launch(w->qk, 2 * D, w->vt, w->att, D, B, T, H, w->Tpad, w->dtype, s);
+      mia_prof_end(w->ctx, rec);
+      if (arc) return mia_fail(w->ctx, MIA_ERR_DEVICE, "attention launch failed");
+    }
     {
       GemmArgs g;
       g.A = w->att; g.lda = D; g.W = b.out.w; g.bias = b.out.b;
@@ -119,7 +135,7 @@ int whisper_encode_from_padded_mel(mia_whisper* w, int B) {
       g.M = M; g.N = D; g.K = D;
       if ((rc = gemm(w, g)) != MIA_OK) return rc;
     }
-    if (mia_norm_launch(w->x, D, b.mlp_ln.g, b.mlp_ln.b, w->h, D, M, D, 1e-5f, false, w->dtype, s)) return mia_fail(w->ctx, MIA_ERR_DEVICE, "norm launch failed");
+    if ((rc = norm(w, b.mlp_ln, w->h, M, D)) != MIA_OK) return rc;
     {
       GemmArgs g;
       g.A = w->h; g.lda = D; g.W = b.mlp1.w; g.bias = b.mlp1.b; g.act = MIA_ACT_GELU;
@@ -134,7 +150,7 @@ int whisper_encode_from_padded_mel(mia_whisper* w, int B) {
       if ((rc = gemm(w, g)) != MIA_OK) return rc;
     }
   }
-  if (mia_norm_launch(w->x, D, w->ln_post.g, w->ln_post.b, w->feat, D, M, D, 1e-5f, false, w->dtype, s)) return mia_fail(w->ctx, MIA_ERR_DEVICE, "norm launch failed");
+  if ((rc = norm(w, w->ln_post, w->feat, M, D)) != MIA_OK) return rc;
   // cross-attention K/V of every decoder layer, head-major [L][B][H][T][64]
   for (int l = 0; l < d.n_text_layer; ++l) {
     const DecBlockW& b = w->dec[l];
@@ -144,7 +160,7 @@ int whisper_encode_from_padded_mel(mia_whisper* w, int B) {
       g.A = w->feat; g.lda = D; g.W = kv ? b.cv.w : b.ck.w; g.bias = kv ? b.cv.b : b.ck.b;
       g.C = (uint16_t*)(kv ? w->cross_v : w->cross_k) + off;
       g.M = M; g.N = D; g.K = D; g.epi = MIA_EPI_HEADMAJOR; g.T = T; g.H = H;
-      if ((rc = gemm(w, g)) != MIA_OK) return rc;
+      if ((rc = gemm(w, g, MIA_PROF_CROSSKV_GEMM)) != MIA_OK) return rc;
     }
   }
   w->cur_B = B;

@@ -155,6 +155,7 @@ extern "C" mia_whisper* mia_whisper_load(mia_ctx* ctx, const mia_whisper_dims* d
     return fail("n_audio_state must equal 64 * n_audio_head (Whisper head dim is 64)");
   if (d.n_text_state % 64 || d.n_text_head * 64 != d.n_text_state) return fail("n_text_state must equal 64 * n_text_head");
   if (d.n_text_state != d.n_audio_state) return fail("n_text_state must equal n_audio_state");
+  if (d.n_text_state > 2048) return fail("n_text_state must be <= 2048 (decode row kernels keep a row in registers)");
   if (d.n_mels <= 0 || d.n_mels > 128 || d.n_mels % 8) return fail("n_mels must be a multiple of 8 in 8..128");
   if (d.n_audio_ctx <= 0 || d.n_audio_ctx % 4) return fail("n_audio_ctx must be a positive multiple of 4");
   if (d.n_vocab <= 0 || d.n_text_ctx <= 0 || d.n_audio_layer <= 0 || d.n_text_layer <= 0) return fail("bad dims");

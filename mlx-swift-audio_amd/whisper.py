@@ -253,6 +253,21 @@ class WhisperModel:
         return [DecodingResult(tokens[b, :n[b]].tolist(), float(avg[b]), float(nsp[b])) for b in range(B)]
 
 
+    def transcribe_windows_device(self, pcm_ptr: int, offs: np.ndarray, o: DecodingOptions, tokens_ptr: int, n_ptr: int,
+                                  avg_ptr: int, nsp_ptr: int, pad_right: int = _audio.N_SAMPLES, _cache={}) -> None:
+        """Same as transcribe_windows but every buffer already lives in HBM (raw device pointers, e.g. torch
+        tensor.data_ptr()); nothing is copied and the call only enqueues work on the ctx stream (plus the small
+        host syncs of the decode loop's early-exit poll)."""
+        offs = np.ascontiguousarray(offs, np.int64)
+        key = id(o)
+        if key not in _cache:
+            _cache[key] = self._opts(o)
+        co, keep = _cache[key]
+        self.B = len(offs) - 1
+        self.ctx.check(self.ctx.lib.mia_whisper_transcribe_windows(self.h, pcm_ptr, offs.ctypes.data, self.B, pad_right, C.byref(co),
+                                                                   tokens_ptr, n_ptr, avg_ptr, nsp_ptr, _lib.MEM_DEVICE))
+
+
 class GreedyDecoder:
     """GreedyDecoder(model:tokenizer:options:).decode(mel) (WhisperDecoding.swift:80-389), batched."""
 

@@ -171,8 +171,6 @@ def s3_log_mel_spectrogram(audio: np.ndarray, n_mels: int = 128, padding: int = 
 
 
 def synth_clip(i: int, n_samples: int = N_SAMPLES) -> np.ndarray:
-    """SURVEY.md section 8d synthetic clip i: 0.1*N(0,1) PCG64(seed 1000+i) + 0.2*sin(2*pi*220*(1+i%8)*t), clipped."""
-    rng = np.random.Generator(np.random.PCG64(1000 + i))
-    t = np.arange(n_samples, dtype=np.float64) / SAMPLE_RATE
-    x = 0.1 * rng.standard_normal(n_samples) + 0.2 * np.sin(2 * np.pi * (220.0 * (1 + i % 8)) * t)
-    return np.clip(x, -1.0, 1.0).astype(f32)
+    """SURVEY.md section 8d synthetic clip i (generator shared with the benchmark)."""
+    from mlx_swift_audio_amd.synthetic import synth_clip as _sc
+    return _sc(i, n_samples)

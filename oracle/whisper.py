@@ -24,37 +24,10 @@ from dataclasses import dataclass, field
 import numpy as np
 import torch
 
+from mlx_swift_audio_amd.synthetic import (DIMS, ModelDimensions, round_array, synthetic_suppress_list,  # noqa: F401
+                                           synthetic_weights, weight_names)
+
 torch.set_grad_enabled(False)
-
-
-@dataclass
-class ModelDimensions:
-    """WhisperConfig.swift:9-86"""
-    n_mels: int
-    n_audio_ctx: int
-    n_audio_state: int
-    n_audio_head: int
-    n_audio_layer: int
-    n_vocab: int
-    n_text_ctx: int
-    n_text_state: int
-    n_text_head: int
-    n_text_layer: int
-
-    def astuple(self):
-        return (self.n_mels, self.n_audio_ctx, self.n_audio_state, self.n_audio_head, self.n_audio_layer,
-                self.n_vocab, self.n_text_ctx, self.n_text_state, self.n_text_head, self.n_text_layer)
-
-
-# public OpenAI dims (SURVEY.md section 8): not in the reference tree, read from config.json at load time there
-DIMS = {
-    "tiny.en": ModelDimensions(80, 1500, 384, 6, 4, 51864, 448, 384, 6, 4),
-    "large-v3-turbo": ModelDimensions(128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 4),
-    "large-v3": ModelDimensions(128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 32),
-    # reduced-size layouts for tests (same vocabulary arithmetic as tiny.en / multilingual)
-    "micro.en": ModelDimensions(80, 100, 128, 2, 2, 51864, 448, 128, 2, 2),
-    "micro": ModelDimensions(128, 100, 128, 2, 2, 51866, 448, 128, 2, 2),
-}
 
 
 @dataclass
@@ -100,98 +73,12 @@ class SpecialTokens:
         return seq
 
 
-def synthetic_suppress_list(st: SpecialTokens, n: int = 90, seed: int = 11) -> list[int]:
-    """The real non-speech list needs the tiktoken vocabulary (WhisperTokenizer.swift:489-532), absent offline:
-    a fixed synthetic list of text ids + the specials GreedyDecoder always adds (:190-198)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    ids = sorted(int(i) for i in rng.choice(st.eot, size=n, replace=False))
-    return ids + [st.transcribe, st.translate, st.sot, st.sot_prev, st.sot_lm, st.no_speech]
-
-
 def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.ndarray:
     """AudioEncoder.swift:78-96 in fp32."""
     inc = np.float32(math.log(max_timescale)) / np.float32(channels // 2 - 1)
     inv = np.exp(-inc * np.arange(channels // 2, dtype=np.float32)).astype(np.float32)
     st = (np.arange(length, dtype=np.float32)[:, None] * inv[None, :]).astype(np.float32)
     return np.concatenate([np.sin(st), np.cos(st)], axis=1).astype(np.float32)
-
-
-def weight_names(d: ModelDimensions) -> dict[str, tuple]:
-    """Reference checkpoint schema (Module property paths) -> shapes."""
-    D, M = d.n_audio_state, d.n_mels
-    out: dict[str, tuple] = {
-        "encoder.conv1.weight": (D, 3, M), "encoder.conv1.bias": (D,),
-        "encoder.conv2.weight": (D, 3, D), "encoder.conv2.bias": (D,),
-        "encoder.ln_post.weight": (D,), "encoder.ln_post.bias": (D,),
-        "decoder.token_embedding.weight": (d.n_vocab, D),
-        "decoder.positional_embedding": (d.n_text_ctx, D),
-        "decoder.ln.weight": (D,), "decoder.ln.bias": (D,),
-    }
-
-    def block(p, cross):
-        names = {}
-        for a in (["attn"] + (["cross_attn"] if cross else [])):
-            names[f"{p}.{a}.query.weight"] = (D, D); names[f"{p}.{a}.query.bias"] = (D,)
-            names[f"{p}.{a}.key.weight"] = (D, D)
-            names[f"{p}.{a}.value.weight"] = (D, D); names[f"{p}.{a}.value.bias"] = (D,)
-            names[f"{p}.{a}.out.weight"] = (D, D); names[f"{p}.{a}.out.bias"] = (D,)
-            names[f"{p}.{a}_ln.weight"] = (D,); names[f"{p}.{a}_ln.bias"] = (D,)
-        names[f"{p}.mlp1.weight"] = (4 * D, D); names[f"{p}.mlp1.bias"] = (4 * D,)
-        names[f"{p}.mlp2.weight"] = (D, 4 * D); names[f"{p}.mlp2.bias"] = (D,)
-        names[f"{p}.mlp_ln.weight"] = (D,); names[f"{p}.mlp_ln.bias"] = (D,)
-        return names
-
-    for l in range(d.n_audio_layer):
-        out.update(block(f"encoder.blocks.{l}", False))
-    for l in range(d.n_text_layer):
-        out.update(block(f"decoder.blocks.{l}", True))
-    return out
-
-
-def _key_seed(name: str, seed: int) -> int:
-    h = 2166136261
-    for ch in name.encode():
-        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
-    return (h + seed * 0x9E3779B1) & 0xFFFFFFFF
-
-
-def synthetic_weights(d: ModelDimensions, seed: int = 0, style: str = "lecun", round_to: str | None = None) -> dict[str, np.ndarray]:
-    """Seeded random-init checkpoint with the reference's key schema.
-    style 'survey': N(0, 0.02^2) matrices, LN gamma 1 beta 0.
-    style 'lecun' : N(0, 1/fan_in) matrices, small random biases / LN affine -- O(1) activations, harder test.
-    round_to: None | 'bf16' | 'f16' rounds every tensor to that storage type (still returned as fp32)."""
-    w: dict[str, np.ndarray] = {}
-    for name, shape in weight_names(d).items():
-        rng = np.random.Generator(np.random.PCG64(_key_seed(name, seed)))
-        is_ln = "_ln." in name or ".ln." in name or "ln_post" in name
-        if is_ln and name.endswith(".weight"):
-            a = np.ones(shape, np.float32) if style == "survey" else (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
-        elif name.endswith(".bias"):
-            a = np.zeros(shape, np.float32) if style == "survey" else (0.1 * rng.standard_normal(shape)).astype(np.float32)
-        else:
-            if style == "survey":
-                std = 0.02
-            elif name == "decoder.token_embedding.weight":
-                std = 1.0 / math.sqrt(shape[-1]) * 4.0     # spread logits: larger argmax margins
-            elif name == "decoder.positional_embedding":
-                std = 0.02
-            else:
-                fan_in = int(np.prod(shape[1:]))
-                std = 1.0 / math.sqrt(fan_in)
-            a = (std * rng.standard_normal(shape)).astype(np.float32)
-        w[name] = round_array(a, round_to)
-    return w
-
-
-def round_array(a: np.ndarray, kind: str | None) -> np.ndarray:
-    if kind is None or kind == "f32":
-        return np.ascontiguousarray(a, np.float32)
-    t = torch.from_numpy(np.ascontiguousarray(a, np.float32))
-    if kind == "bf16":
-        return t.to(torch.bfloat16).to(torch.float32).numpy()
-    if kind == "f16":
-        return t.to(torch.float16).to(torch.float32).numpy()
-    raise ValueError(kind)
 
 
 def _t(a):
