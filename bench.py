@@ -121,12 +121,12 @@ def main():
     n_tok = torch.zeros(B, dtype=torch.int32, device="cuda")
     avg = torch.zeros(B, dtype=torch.float32, device="cuda")
     nsp = torch.zeros(B, dtype=torch.float32, device="cuda")
-    gathered = [torch.zeros_like(tokens) for _ in range(world)] if world > 1 else None
+    from mlx_swift_audio_amd import parallel as P
 
     def step():
         model.transcribe_windows_device(pcm.data_ptr(), offs, opts, tokens.data_ptr(), n_tok.data_ptr(), avg.data_ptr(), nsp.data_ptr())
         if world > 1:
-            dist.all_gather(gathered, tokens)          # the path's only exchange: token ids over xGMI (RCCL)
+            P.gather_tokens(tokens, n_tok, world, max_shard=B)   # the path's only exchange: token ids over xGMI (RCCL)
 
     def fence():
         if world > 1:

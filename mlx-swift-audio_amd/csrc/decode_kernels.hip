@@ -118,94 +118,112 @@ __global__ __launch_bounds__(256) void dec_reduce_ln(const float* __restrict__ p
 // One wave per 16 output columns and K-slice; weights go HBM -> VGPR (each weight byte is read exactly once),
 // activations come from L2; v_mfma_f32_16x16x32 with W as the row operand so a lane owns 4 consecutive n.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MODE>
+// NT = 16-column tiles per wave (activation fragments are reused NT times: NT=4 for the 51866-wide logits GEMM,
+// where the L2->CU activation traffic would otherwise be twice the HBM weight traffic); KB = K-steps per batch.
+template <typename T, int MODE, int NT, int KB>
 __global__ __launch_bounds__(64) void dec_skinny_gemm(SkinnyArgs a) {
   const int lane = threadIdx.x;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * (16 * NT);
   const int split = blockIdx.y;
   const int m0 = blockIdx.z * 32;
   const int Kc = a.K / a.S;
   const int kbeg = split * Kc;
   const int r = lane & 15, c = lane >> 4;
-  int wn = n0 + r; wn = wn < a.N ? wn : a.N - 1;
+  const uint16_t* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int wn = n0 + 16 * t + r; wn = wn < a.N ? wn : a.N - 1;
+    wp[t] = a.W + (int64_t)wn * a.K + kbeg + 8 * c;
+  }
   int am0 = m0 + r; am0 = am0 < a.M ? am0 : a.M - 1;
   int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
-  const uint16_t* wp = a.W + (int64_t)wn * a.K + kbeg + 8 * c;
   const uint16_t* ap0 = a.A + (int64_t)am0 * a.lda + kbeg + 8 * c;
   const uint16_t* ap1 = a.A + (int64_t)am1 * a.lda + kbeg + 8 * c;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  // Software-pipelined register double buffer: batch i+1 (4 K-steps = 12 independent 16-byte loads per lane) is
-  // issued before the MFMAs of batch i, so ~24 loads per lane stay in flight (weights are HBM-once traffic).
-  struct Batch { s16x8 w[4], a0[4], a1[4]; };
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  // Software-pipelined register double buffer: batch i+1 (KB K-steps) is issued before the MFMAs of batch i, so two
+  // batches of independent 16-byte loads stay in flight per lane (weights are HBM-once traffic).
+  struct Batch { s16x8 w[KB][NT], a0[KB], a1[KB]; };
   auto load_batch = [&](Batch& t, int k) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      t.w[u] = *reinterpret_cast<const s16x8*>(wp + k + 32 * u);
+    for (int u = 0; u < KB; ++u) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) t.w[u][n] = *reinterpret_cast<const s16x8*>(wp[n] + k + 32 * u);
       t.a0[u] = *reinterpret_cast<const s16x8*>(ap0 + k + 32 * u);
       t.a1[u] = *reinterpret_cast<const s16x8*>(ap1 + k + 32 * u);
     }
   };
   auto mma_batch = [&](const Batch& t) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc0 = T::mfma16(t.w[u], t.a0[u], acc0);
-      acc1 = T::mfma16(t.w[u], t.a1[u], acc1);
-    }
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[n][0] = T::mfma16(t.w[u][n], t.a0[u], acc[n][0]);
+        acc[n][1] = T::mfma16(t.w[u][n], t.a1[u], acc[n][1]);
+      }
   };
-  const int nb = Kc / 128;
+  constexpr int KSTEP = 32 * KB;
+  const int nb = Kc / KSTEP;
   int k = 0;
   if (nb > 0) {
     Batch b0, b1;
     load_batch(b0, 0);
     int i = 0;
     for (; i + 2 <= nb - 1; i += 2) {      // two batches per trip so both buffers keep static register names
-      load_batch(b1, (i + 1) * 128);
+      load_batch(b1, (i + 1) * KSTEP);
       mma_batch(b0);
-      load_batch(b0, (i + 2) * 128);
+      load_batch(b0, (i + 2) * KSTEP);
       mma_batch(b1);
     }
     if (i + 1 <= nb - 1) {
-      load_batch(b1, (i + 1) * 128);
+      load_batch(b1, (i + 1) * KSTEP);
       mma_batch(b0);
       mma_batch(b1);
     } else {
       mma_batch(b0);
     }
-    k = nb * 128;
+    k = nb * KSTEP;
   }
   for (; k < Kc; k += 32) {
-    const s16x8 fw = *reinterpret_cast<const s16x8*>(wp + k);
     const s16x8 fa0 = *reinterpret_cast<const s16x8*>(ap0 + k);
     const s16x8 fa1 = *reinterpret_cast<const s16x8*>(ap1 + k);
-    acc0 = T::mfma16(fw, fa0, acc0);
-    acc1 = T::mfma16(fw, fa1, acc1);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const s16x8 fw = *reinterpret_cast<const s16x8*>(wp[n] + k);
+      acc[n][0] = T::mfma16(fw, fa0, acc[n][0]);
+      acc[n][1] = T::mfma16(fw, fa1, acc[n][1]);
+    }
   }
-  // lane holds C[m = m0 + mt*16 + r][n = n0 + 4c + j]
-  const int n = n0 + 4 * c;
+  // lane holds C[m = m0 + mt*16 + r][n = n0 + 16t + 4c + j]
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int m = m0 + mt * 16 + r;
-    if (m >= a.M) continue;
-    const f32x4 acc = mt ? acc1 : acc0;
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + 4 * c;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (n + j >= a.N) continue;
-      float v = acc[j];
-      if (MODE == SK_PARTIAL) {
-        reinterpret_cast<float*>(a.out)[((int64_t)split * a.M + m) * a.N + n + j] = v;
-        continue;
-      }
-      if (a.bias) v += a.bias[n + j];
-      if (a.act == MIA_ACT_GELU) v = gelu_erf(v);
-      if (MODE == SK_OUTF32) reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n + j] = v;
-      else if (MODE == SK_OUT16) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + n + j] = T::from_f32(v);
-      else {  // SK_QKV: [0,D) -> q, [D,2D) -> self K cache, [2D,3D) -> self V cache at position pos
-        const int nn = n + j;
-        if (nn < a.D) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + nn] = T::from_f32(v);
-        else {
-          const int hd = (nn - a.D) % a.D, h = hd >> 6, d = hd & 63;
-          uint16_t* cache = nn < 2 * a.D ? a.cache_k : a.cache_v;
-          cache[(((int64_t)m * a.H + h) * a.n_ctx + a.st->pos) * 64 + d] = T::from_f32(v);
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = m0 + mt * 16 + r;
+      if (m >= a.M) continue;
+      const f32x4 av = acc[t][mt];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (n + j >= a.N) continue;
+        float v = av[j];
+        if (MODE == SK_PARTIAL) {
+          reinterpret_cast<float*>(a.out)[((int64_t)split * a.M + m) * a.N + n + j] = v;
+          continue;
+        }
+        if (a.bias) v += a.bias[n + j];
+        if (a.act == MIA_ACT_GELU) v = gelu_erf(v);
+        if (MODE == SK_OUTF32) reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n + j] = v;
+        else if (MODE == SK_OUT16) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + n + j] = T::from_f32(v);
+        else {  // SK_QKV: [0,D) -> q, [D,2D) -> self K cache, [2D,3D) -> self V cache at position pos
+          const int nn = n + j;
+          if (nn < a.D) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + nn] = T::from_f32(v);
+          else {
+            const int hd = (nn - a.D) % a.D, h = hd >> 6, d = hd & 63;
+            uint16_t* cache = nn < 2 * a.D ? a.cache_k : a.cache_v;
+            cache[(((int64_t)m * a.H + h) * a.n_ctx + a.st->pos) * 64 + d] = T::from_f32(v);
+          }
         }
       }
     }
@@ -324,9 +342,10 @@ struct HeadBufs {
   int32_t* n_logprob;           // [B]
   float* no_speech;             // [B]
   const uint32_t* suppress;     // [2][nw]
-  const DecState* st;
+  DecState* st;
 };
 
+constexpr int HEAD_NPT = 52;   // logits per thread held in registers: V <= 1024 * 52
 struct ArgMax { float v; int i; };
 __device__ __forceinline__ ArgMax amax(ArgMax a, ArgMax b) {   // larger value wins, lowest index wins ties (MLX argMax)
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
@@ -343,6 +362,16 @@ __device__ __forceinline__ ArgMax wave_amax(ArgMax a) {
 // Two passes over the clip's logits (L2 resident): pass 1 = every max / argmax, pass 2 = every exp-sum.
 // The timestamp heuristic (:299-322) decides between two precomputed candidates: A = rules only, B = rules + "text
 // suppressed".  log-sum-exps use the max-shifted form; ts_lse = (max_ts - lse) + log(sum_ts exp(x - max_ts)).
+// Every block reads st->pos first; the block that draws the last ticket (all others have read pos long before they
+// take theirs) advances the position for the next step, so no separate "advance" launch is needed.
+__device__ __forceinline__ void head_ticket(DecState* st, int B) {
+  __syncthreads();                                    // every wave of this block has read st->pos by now
+  if (threadIdx.x == 0) {
+    const int t = atomicAdd(&st->active, 1);
+    if (t == B - 1) { st->active = 0; st->pos += 1; }
+  }
+}
+
 __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
   __shared__ float shf[16][4];
   __shared__ float sha[16][2];
@@ -354,10 +383,10 @@ __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
   const int cur_len = pos + 1;
   int32_t* toks = hb.tokens + (int64_t)b * p.n_ctx;
   const bool generating = cur_len >= p.n_initial;
-  if (!generating && pos != p.sot_index) return;      // forced token and no probe wanted: nothing to do
+  if (!generating && pos != p.sot_index) { head_ticket(hb.st, p.B); return; }   // forced token, no probe: nothing to do
   if (generating && hb.finished[b]) {
     if (tid == 0 && cur_len < p.n_ctx) toks[cur_len] = p.eot;
-    if (pos != p.sot_index) return;
+    if (pos != p.sot_index) { head_ticket(hb.st, p.B); return; }
   }
   const bool decide = generating && !hb.finished[b];
   const int num_gen = cur_len - p.n_initial;          // == loop iteration of the reference
@@ -396,22 +425,23 @@ __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
     return false;
   };
 
+  // ---- the clip's logits are read ONCE: 52 registers per thread (V <= 53248), all loads in flight together
+  float x[HEAD_NPT];
+#pragma unroll
+  for (int u = 0; u < HEAD_NPT; ++u) { const int i = tid + 1024 * u; x[u] = i < V ? lg[i] : -INFINITY; }
   // ---- pass 1: maxima
   float mx_text = -INFINITY, mx_ts = -INFINITY;
   ArgMax bA{-INFINITY, 0x7fffffff}, bB{-INFINITY, 0x7fffffff};
-  for (int i0 = tid; i0 < V; i0 += 4096) {
-    float x[4];
+  unsigned long long okA = 0ull;                      // bit u: element u is unmasked under the rules (hypothesis A)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = i0 + 1024 * u; x[u] = i < V ? lg[i] : -INFINITY; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + 1024 * u;
-      if (i >= V) continue;
-      if (i >= tsb) mx_ts = fmaxf(mx_ts, x[u]); else mx_text = fmaxf(mx_text, x[u]);
-      if (decide && !maskedA(i)) {
-        bA = amax(bA, ArgMax{x[u], i});
-        if (i >= tsb) bB = amax(bB, ArgMax{x[u], i});
-      }
+  for (int u = 0; u < HEAD_NPT; ++u) {
+    const int i = tid + 1024 * u;
+    if (i >= V) continue;
+    if (i >= tsb) mx_ts = fmaxf(mx_ts, x[u]); else mx_text = fmaxf(mx_text, x[u]);
+    if (decide && !maskedA(i)) {
+      okA |= 1ull << u;
+      bA = amax(bA, ArgMax{x[u], i});
+      if (i >= tsb) bB = amax(bB, ArgMax{x[u], i});
     }
   }
   mx_text = wave_max(mx_text); mx_ts = wave_max(mx_ts);
@@ -426,27 +456,23 @@ __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
   const float mx_all = fmaxf(mx_text, mx_ts);
   __syncthreads();
 
-  // ---- pass 2: exp-sums
+  // ---- pass 2: exp-sums (registers)
   float s_all = 0.f, s_ts = 0.f, fA = 0.f, fB = 0.f;
-  for (int i0 = tid; i0 < V; i0 += 4096) {
-    float x[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = i0 + 1024 * u; x[u] = i < V ? lg[i] : -INFINITY; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + 1024 * u;
-      if (i >= V) continue;
-      s_all += __expf(x[u] - mx_all);
-      if (heuristic && i >= tsb) s_ts += __expf(x[u] - mx_ts);
-      if (decide && !maskedA(i)) {
-        fA += __expf(x[u] - bA.v);
-        if (heuristic && i >= tsb) fB += __expf(x[u] - bB.v);
-      }
+  for (int u = 0; u < HEAD_NPT; ++u) {
+    const int i = tid + 1024 * u;
+    if (i >= V) continue;
+    s_all += __expf(x[u] - mx_all);
+    if (heuristic && i >= tsb) s_ts += __expf(x[u] - mx_ts);
+    if ((okA >> u) & 1ull) {
+      fA += __expf(x[u] - bA.v);
+      if (heuristic && i >= tsb) fB += __expf(x[u] - bB.v);
     }
   }
   s_all = wave_sum(s_all); s_ts = wave_sum(s_ts); fA = wave_sum(fA); fB = wave_sum(fB);
   if (lane == 0) { shf[wave][0] = s_all; shf[wave][1] = s_ts; shf[wave][2] = fA; shf[wave][3] = fB; }
   __syncthreads();
+  head_ticket(hb.st, p.B);
   if (tid != 0) return;
   s_all = s_ts = fA = fB = 0.f;
   for (int w2 = 0; w2 < 16; ++w2) { s_all += shf[w2][0]; s_ts += shf[w2][1]; fA += shf[w2][2]; fB += shf[w2][3]; }
@@ -518,12 +544,17 @@ int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln
 
 template <typename T>
 static void skinny_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
-  dim3 grid((a.N + 15) / 16, a.S, (a.M + 31) / 32), block(64);
+  dim3 block(64);
+  if (mode == SK_OUTF32) {   // the vocabulary-wide logits GEMM: 64 columns per wave
+    dim3 grid((a.N + 63) / 64, a.S, (a.M + 31) / 32);
+    hipLaunchKernelGGL((dec_skinny_gemm<T, SK_OUTF32, 4, 2>), grid, block, 0, s, a);
+    return;
+  }
+  dim3 grid((a.N + 15) / 16, a.S, (a.M + 31) / 32);
   switch (mode) {
-    case SK_OUT16: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_OUT16>), grid, block, 0, s, a); break;
-    case SK_OUTF32: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_OUTF32>), grid, block, 0, s, a); break;
-    case SK_PARTIAL: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_PARTIAL>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_QKV>), grid, block, 0, s, a); break;
+    case SK_OUT16: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_OUT16, 1, 4>), grid, block, 0, s, a); break;
+    case SK_PARTIAL: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_PARTIAL, 1, 4>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_QKV, 1, 4>), grid, block, 0, s, a); break;
   }
 }
 
@@ -545,9 +576,9 @@ int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const vo
 }
 
 int dec_launch_head(mia_whisper* w, int32_t* last_ts, const DecodeParams& p, hipStream_t s) {
+  if (p.V > 1024 * HEAD_NPT) return -1;
   HeadBufs hb{w->logits, w->tokens, w->n_gen, w->finished, last_ts, w->sum_logprob, w->n_logprob, w->no_speech, w->suppress_bits, w->state};
   hipLaunchKernelGGL(dec_head, dim3(w->cur_B), dim3(1024), 0, s, hb, p);
-  hipLaunchKernelGGL(dec_advance, dim3(1), dim3(1), 0, s, w->state);
   return 0;
 }
 

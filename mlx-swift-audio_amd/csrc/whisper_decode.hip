@@ -52,7 +52,7 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p) {
     LinearW e; e.w = w->tok_emb; e.N = p.V; e.K = D;
     if (skinny(dh, D, e, false, w->logits, p.V, 1, MIA_ACT_NONE, SK_OUTF32)) return -1;
   }
-  dec_launch_head(w, w->last_ts, p, s);
+  if (dec_launch_head(w, w->last_ts, p, s)) return -1;
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
