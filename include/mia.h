@@ -86,6 +86,15 @@ int mia_logmel_whisper(mia_ctx* ctx, const float* pcm, const int64_t* offs, int 
 int mia_logmel_s3(mia_ctx* ctx, const float* pcm, const int64_t* offs, int B, int n_mels,
                   int64_t pad_right, int64_t n_frames_out, void* mel, int out_dtype, int mem);
 
+/* ---- operator level -------------------------------------------------------------------------- */
+/* y = act(x W^T + b) + r : the dense contraction behind every MLXNN Linear on the path
+ * (e.g. STT/Whisper/Layers/MultiHeadAttention.swift:40-58,134; ResidualAttentionBlock.swift:91).
+ *   x [M][lda] and w [N][K] in `dtype` (MIA_BF16|MIA_F16), y [M][ldy] in `dtype` or fp32 (out_f32),
+ *   bias fp32 [N] or NULL, r fp32 [M][ldr] or NULL, act 0 = none / 1 = exact-erf GELU.  K % 64 == 0.
+ *   variant 0 = register-staged tiles, 1 = LDS-DMA staged tiles (default elsewhere).  Buffers live in `mem`. */
+int mia_op_linear(mia_ctx* ctx, const void* x, int64_t lda, const void* w, const float* bias, const float* r, int64_t ldr,
+                  void* y, int64_t ldy, int M, int N, int K, int act, int dtype, int out_f32, int variant, int mem);
+
 /* ---- Whisper ---------------------------------------------------------------------------------- */
 /* Model dimensions == ModelDimensions (STT/Whisper/Config/WhisperConfig.swift:9-86), read by the caller
  * from config.json. */

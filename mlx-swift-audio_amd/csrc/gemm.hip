@@ -25,7 +25,75 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return act == MIA_ACT_GELU ? gelu_erf(v) : v;
 }
 
+__device__ __forceinline__ void glds16(const void* g, void* l) {   // async 16 B/lane HBM -> LDS (wave-uniform LDS base + lane*16)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// One lane's 4 consecutive output columns (n .. n+3) of row m: bias, activation, residual, store in the epilogue's layout.
 template <typename T, bool OUT_F32, int EPI>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int bz, int m, int n, const f32x4& a, bool vec_ok) {
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = a[j];
+  if (g.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += g.bias[n + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(v[j], g.act);
+  if (g.R) {
+    const float* r = g.R + (int64_t)bz * g.strideR + (int64_t)m * g.ldr + n;
+    if (vec_ok) {
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += rv[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += r[j];
+    }
+  }
+  if (EPI == MIA_EPI_STD) {
+    if (OUT_F32) {
+      float* c = reinterpret_cast<float*>(g.C) + (int64_t)bz * g.strideC + (int64_t)m * g.ldc + n;
+      if (vec_ok) *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n + j < g.N) c[j] = v[j];
+      }
+    } else {
+      uint16_t* c = reinterpret_cast<uint16_t*>(g.C) + (int64_t)bz * g.strideC + (int64_t)m * g.ldc + n;
+      if (vec_ok) *reinterpret_cast<u32x2*>(c) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n + j < g.N) c[j] = T::from_f32(v[j]);
+      }
+    }
+  } else if (EPI == MIA_EPI_QKV_VT) {
+    // columns [0, 2D): q|k rows, row stride ldc.  columns [2D, 3D): V, stored transposed per head:
+    // vt[((b*H + h)*64 + d) * Tpad + t]   (m = b*T + t, n - 2D = h*64 + d)
+    const int D2 = 2 * g.H * 64;
+    if (n < D2) {
+      uint16_t* c = reinterpret_cast<uint16_t*>(g.C) + (int64_t)m * g.ldc + n;
+      *reinterpret_cast<u32x2*>(c) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+    } else {
+      const int b = m / g.T, t = m - b * g.T;
+      const int hd = n - D2;   // h*64 + d
+      uint16_t* vt = reinterpret_cast<uint16_t*>(g.C2) + ((int64_t)b * g.H * 64 + hd) * g.Tpad + t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vt[(int64_t)j * g.Tpad] = T::from_f32(v[j]);
+    }
+  } else {  // MIA_EPI_HEADMAJOR: out[((b*H + h)*T + t)*64 + d], n = h*64 + d (4 consecutive n share a head)
+    const int b = m / g.T, t = m - b * g.T;
+    const int h = n >> 6, d = n & 63;
+    uint16_t* c = reinterpret_cast<uint16_t*>(g.C) + (((int64_t)b * g.H + h) * g.T + t) * 64 + d;
+    *reinterpret_cast<u32x2*>(c) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+  }
+}
+
+// STAGE 0: HBM -> registers -> LDS (issue early, write late).  STAGE 1: LDS-DMA (global_load_lds_dwordx4): the LDS image is
+// lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address; no staging registers, no ds_write pass.
+template <typename T, bool OUT_F32, int EPI, int STAGE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [2 buffers][A|W]
   const int tid = threadIdx.x;
@@ -49,20 +117,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   const uint16_t* __restrict__ A = reinterpret_cast<const uint16_t*>(g.A) + (int64_t)bz * g.strideA;
   const uint16_t* __restrict__ W = reinterpret_cast<const uint16_t*>(g.W);
 
-  // ---- staging: each thread moves 4 x 16 B of A and 4 x 16 B of W per K-step
-  const int s_row = tid >> 3;          // 0..31 (+32*i)
-  const int s_chk = tid & 7;           // 16-B chunk within the 128-B row
+  // ---- staging: each thread moves 4 x 16 B of A and 4 x 16 B of W per K-step.
+  // Piece i of this wave covers tile rows 32*wave + 8*i + (lane>>3); lane&7 is the 16-B position inside the 128-B row,
+  // which holds logical chunk (lane&7) ^ (row&7).
+  const int s_pos = lane & 7;
   const uint16_t* a_src[4];
   const uint16_t* w_src[4];
   int s_dst[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = s_row + 32 * i;
+    const int row = 32 * wave + 8 * i + (lane >> 3);
+    const int chk = s_pos ^ (row & 7);
     int am = m0 + row; am = am < g.M ? am : g.M - 1;      // clamp: tail rows are computed but never stored
     int wn = n0 + row; wn = wn < g.N ? wn : g.N - 1;
-    a_src[i] = A + (int64_t)am * g.lda + s_chk * 8;
-    w_src[i] = W + (int64_t)wn * g.K + s_chk * 8;
-    s_dst[i] = row * 128 + ((s_chk ^ (row & 7)) << 4);
+    a_src[i] = A + (int64_t)am * g.lda + chk * 8;
+    w_src[i] = W + (int64_t)wn * g.K + chk * 8;
+    s_dst[i] = row * 128 + (s_pos << 4);                  // == (32*wave + 8*i)*128 + lane*16: lane-linear per piece
   }
   u32x4 ra[4], rw[4];
   auto load_regs = [&](int k0) {
@@ -80,6 +150,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
       *reinterpret_cast<u32x4*>(base + TILE_BYTES + s_dst[i]) = rw[i];
     }
   };
+  auto stage_dma = [&](int buf, int k0) {
+    char* base = lds + buf * 2 * TILE_BYTES + (32 * wave) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(a_src[i] + k0, base + i * 1024);
+      glds16(w_src[i] + k0, base + TILE_BYTES + i * 1024);
+    }
+  };
 
   // ---- fragment read addresses (row = base + lane&15, chunk = kk*4 + lane>>4)
   const int f_row = lane & 15, f_chk = lane >> 4;
@@ -90,12 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
-  load_regs(0);
-  write_lds(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_regs((kt + 1) * BK);
+  auto compute = [&](int cur) {
     const char* sa = lds + cur * 2 * TILE_BYTES;
     const char* sw = sa + TILE_BYTES;
 #pragma unroll
@@ -113,9 +186,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = T::mfma16(fw[nt], fa[mt], acc[mt][nt]);  // rows<-n, cols<-m
     }
-    if (kt + 1 < nk) write_lds(cur ^ 1);
+  };
+  int cur = 0;
+  if (STAGE == 0) {
+    load_regs(0);
+    write_lds(0);
     __syncthreads();
-    cur ^= 1;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) load_regs((kt + 1) * BK);
+      compute(cur);
+      if (kt + 1 < nk) write_lds(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    stage_dma(0, 0);
+    __syncthreads();                       // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) stage_dma(cur ^ 1, (kt + 1) * BK);   // the other buffer was last read before the previous barrier
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   // ---- epilogue: lane holds, per (mt,nt), C[m = ..+lane&15][n = ..+(lane>>4)*4 + 0..3]
@@ -129,79 +221,158 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wc * 64 + nt * 16 + e_n;
       if (n >= g.N) continue;
-      float v[4];
+      epilogue_store<T, OUT_F32, EPI>(g, bz, m, n, acc[mt][nt], vec_ok);
+    }
+  }
+}
+
+// ---- 256x256x64 tile, 512 threads = 2(M) x 4(N) waves, each wave 128x64 (32 accumulator tiles), one block per CU.
+// Twice the arithmetic intensity of the 128^2 tile (31 instead of 62 LDS-DMA bytes per MFMA-cycle per CU), which is
+// what the L2 -> LDS path can sustain on 256 CUs.  LDS: 2 stages x (A 32 KB + W 32 KB) = 128 KB, LDS-DMA staged,
+// same swizzle; per K-step a wave runs 64 MFMAs in four 64x32 quadrants so only 8 fragments are live at a time.
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int TILE2_BYTES = BM2 * BK * 2;   // 32 KB per operand tile
+
+template <typename T, bool OUT_F32, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [2 stages][A|W] = 128 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (g.N + BN2 - 1) / BN2;
+  const int tiles_m = (g.M + BM2 - 1) / BM2;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+  const int bz = blockIdx.z;
+  const uint16_t* __restrict__ A = reinterpret_cast<const uint16_t*>(g.A) + (int64_t)bz * g.strideA;
+  const uint16_t* __restrict__ W = reinterpret_cast<const uint16_t*>(g.W);
+
+  const int s_pos = lane & 7;
+  const uint16_t* a_src[4];
+  const uint16_t* w_src[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j];
-      if (g.bias) {
+  for (int i = 0; i < 4; ++i) {
+    const int row = 32 * wave + 8 * i + (lane >> 3);
+    const int chk = s_pos ^ (row & 7);
+    int am = m0 + row; am = am < g.M ? am : g.M - 1;
+    int wn = n0 + row; wn = wn < g.N ? wn : g.N - 1;
+    a_src[i] = A + (int64_t)am * g.lda + chk * 8;
+    w_src[i] = W + (int64_t)wn * g.K + chk * 8;
+  }
+  auto stage_dma = [&](int buf, int k0) {
+    char* base = lds + buf * 2 * TILE2_BYTES + (32 * wave) * 128;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += g.bias[n + j];
+    for (int i = 0; i < 4; ++i) {
+      glds16(a_src[i] + k0, base + i * 1024);
+      glds16(w_src[i] + k0, base + TILE2_BYTES + i * 1024);
+    }
+  };
+  const int f_row = lane & 15, f_chk = lane >> 4;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  auto compute = [&](int cur) {
+    const char* sa = lds + cur * 2 * TILE2_BYTES;
+    const char* sw = sa + TILE2_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      s16x8 fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int wrow = wc * 64 + t * 16 + f_row;
+        fw[t] = *reinterpret_cast<const s16x8*>(sw + wrow * 128 + (((kk * 4 + f_chk) ^ (wrow & 7)) << 4));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(v[j], g.act);
-      if (g.R) {
-        const float* r = g.R + (int64_t)bz * g.strideR + (int64_t)m * g.ldr + n;
-        if (vec_ok) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(r);
+      for (int mh = 0; mh < 2; ++mh) {
+        s16x8 fa[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += rv[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += r[j];
+        for (int t = 0; t < 4; ++t) {
+          const int ar = wr * 128 + mh * 64 + t * 16 + f_row;
+          fa[t] = *reinterpret_cast<const s16x8*>(sa + ar * 128 + (((kk * 4 + f_chk) ^ (ar & 7)) << 4));
         }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[mh * 4 + mt][nt] = T::mfma16(fw[nt], fa[mt], acc[mh * 4 + mt][nt]);
       }
-      if (EPI == MIA_EPI_STD) {
-        if (OUT_F32) {
-          float* c = reinterpret_cast<float*>(g.C) + (int64_t)bz * g.strideC + (int64_t)m * g.ldc + n;
-          if (vec_ok) *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
-          else {
+    }
+  };
+  int cur = 0;
+  stage_dma(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage_dma(cur ^ 1, (kt + 1) * BK);
+    compute(cur);
+    __syncthreads();
+    cur ^= 1;
+  }
+  const int e_m = lane & 15, e_n = (lane >> 4) * 4;
+  const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && (g.R == nullptr || (g.ldr & 3) == 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (n + j < g.N) c[j] = v[j];
-          }
-        } else {
-          uint16_t* c = reinterpret_cast<uint16_t*>(g.C) + (int64_t)bz * g.strideC + (int64_t)m * g.ldc + n;
-          if (vec_ok) *reinterpret_cast<u32x2*>(c) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-          else {
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = m0 + wr * 128 + mt * 16 + e_m;
+    if (m >= g.M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (n + j < g.N) c[j] = T::from_f32(v[j]);
-          }
-        }
-      } else if (EPI == MIA_EPI_QKV_VT) {
-        // columns [0, 2D): q|k rows, row stride ldc.  columns [2D, 3D): V, stored transposed per head:
-        // vt[((b*H + h)*64 + d) * Tpad + t]   (m = b*T + t, n - 2D = h*64 + d)
-        const int D2 = 2 * g.H * 64;
-        if (n < D2) {
-          uint16_t* c = reinterpret_cast<uint16_t*>(g.C) + (int64_t)m * g.ldc + n;
-          *reinterpret_cast<u32x2*>(c) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-        } else {
-          const int b = m / g.T, t = m - b * g.T;
-          const int hd = n - D2;   // h*64 + d
-          uint16_t* vt = reinterpret_cast<uint16_t*>(g.C2) + ((int64_t)b * g.H * 64 + hd) * g.Tpad + t;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) vt[(int64_t)j * g.Tpad] = T::from_f32(v[j]);
-        }
-      } else {  // MIA_EPI_HEADMAJOR: out[((b*H + h)*T + t)*64 + d], n = h*64 + d (4 consecutive n share a head)
-        const int b = m / g.T, t = m - b * g.T;
-        const int h = n >> 6, d = n & 63;
-        uint16_t* c = reinterpret_cast<uint16_t*>(g.C) + (((int64_t)b * g.H + h) * g.T + t) * 64 + d;
-        *reinterpret_cast<u32x2*>(c) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-      }
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wc * 64 + nt * 16 + e_n;
+      if (n >= g.N) continue;
+      epilogue_store<T, OUT_F32, EPI>(g, bz, m, n, acc[mt][nt], vec_ok);
     }
   }
 }
 
 template <typename T>
-int launch_t(const GemmArgs& g, hipStream_t s) {
+int launch_256(const GemmArgs& g, hipStream_t s) {
+  const int tiles = ((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
+  dim3 grid(tiles, 1, g.batch > 0 ? g.batch : 1), block(512);
+  const size_t lds_bytes = 4 * TILE2_BYTES;
+#define L256(F32, E)                                                                                              \
+  do {                                                                                                            \
+    static bool attr = false;                                                                                     \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_256<T, F32, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr = true; } \
+    hipLaunchKernelGGL((gemm_nt_kernel_256<T, F32, E>), grid, block, lds_bytes, s, g);                             \
+  } while (0)
+  if (g.epi == MIA_EPI_STD) { if (g.out_f32) L256(true, MIA_EPI_STD); else L256(false, MIA_EPI_STD); }
+  else if (g.epi == MIA_EPI_QKV_VT) L256(false, MIA_EPI_QKV_VT);
+  else L256(false, MIA_EPI_HEADMAJOR);
+#undef L256
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename T, int STAGE>
+int launch_ts(const GemmArgs& g, hipStream_t s) {
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   dim3 grid(tiles, 1, g.batch > 0 ? g.batch : 1), block(256);
   if (g.epi == MIA_EPI_STD) {
-    if (g.out_f32) hipLaunchKernelGGL((gemm_nt_kernel<T, true, MIA_EPI_STD>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_nt_kernel<T, false, MIA_EPI_STD>), grid, block, 0, s, g);
+    if (g.out_f32) hipLaunchKernelGGL((gemm_nt_kernel<T, true, MIA_EPI_STD, STAGE>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, false, MIA_EPI_STD, STAGE>), grid, block, 0, s, g);
   } else if (g.epi == MIA_EPI_QKV_VT) {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, false, MIA_EPI_QKV_VT>), grid, block, 0, s, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, false, MIA_EPI_QKV_VT, STAGE>), grid, block, 0, s, g);
   } else {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, false, MIA_EPI_HEADMAJOR>), grid, block, 0, s, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, false, MIA_EPI_HEADMAJOR, STAGE>), grid, block, 0, s, g);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename T>
+int launch_t(const GemmArgs& g, hipStream_t s) {
+  if (g.variant == 0) return launch_ts<T, 0>(g, s);
+  if (g.variant == 1) return launch_ts<T, 1>(g, s);
+  if (g.variant == 2) return launch_256<T>(g, s);
+  // auto: the 256^2 tile needs enough tiles to fill 256 CUs; small problems keep the 128^2 tile
+  const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.batch > 0 ? g.batch : 1);
+  return tiles256 >= 256 ? launch_256<T>(g, s) : launch_ts<T, 1>(g, s);
 }
 
 }  // namespace

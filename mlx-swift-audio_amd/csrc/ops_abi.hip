@@ -1,0 +1,37 @@
+// ops_abi.hip -- operator-level C ABI entry points (include/mia.h "operator level").
+#include "gemm.h"
+#include "mia_internal.h"
+#include "ops.h"
+
+extern "C" int mia_op_linear(mia_ctx* ctx, const void* x, int64_t lda, const void* w, const float* bias, const float* r, int64_t ldr,
+                             void* y, int64_t ldy, int M, int N, int K, int act, int dtype, int out_f32, int variant, int mem) {
+  if (!ctx) return MIA_ERR_INVALID_ARGUMENT;
+  MIA_CHECK_ARG(ctx, x && w && y, "op_linear: null pointer");
+  MIA_CHECK_ARG(ctx, dtype == MIA_BF16 || dtype == MIA_F16, "op_linear: dtype must be MIA_BF16 or MIA_F16");
+  MIA_CHECK_ARG(ctx, mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE, "op_linear: bad mem");
+  MIA_CHECK_ARG(ctx, M > 0 && N > 0 && K > 0 && lda >= K && ldy >= N && (!r || ldr >= N), "op_linear: bad shape");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldy; g.ldr = ldr; g.act = act; g.out_f32 = out_f32 ? 1 : 0; g.variant = variant;
+  const size_t xb = (size_t)M * lda * 2, wb = (size_t)N * K * 2, yb = (size_t)M * ldy * (out_f32 ? 4 : 2);
+  const size_t bb = bias ? (size_t)N * 4 : 0, rb = r ? (size_t)M * ldr * 4 : 0;
+  if (mem == MIA_MEM_DEVICE) {
+    g.A = x; g.W = w; g.C = y; g.bias = bias; g.R = r;
+  } else {
+    const size_t o_w = align_up(xb, 256), o_y = o_w + align_up(wb, 256), o_b = o_y + align_up(yb, 256), o_r = o_b + align_up(bb, 256);
+    char* ws = (char*)mia_workspace(ctx, o_r + align_up(rb, 256));
+    if (!ws) return MIA_ERR_OUT_OF_MEMORY;
+    MIA_HIP(ctx, hipMemcpyAsync(ws, x, xb, hipMemcpyHostToDevice, ctx->stream));
+    MIA_HIP(ctx, hipMemcpyAsync(ws + o_w, w, wb, hipMemcpyHostToDevice, ctx->stream));
+    if (bias) MIA_HIP(ctx, hipMemcpyAsync(ws + o_b, bias, bb, hipMemcpyHostToDevice, ctx->stream));
+    if (r) MIA_HIP(ctx, hipMemcpyAsync(ws + o_r, r, rb, hipMemcpyHostToDevice, ctx->stream));
+    g.A = ws; g.W = ws + o_w; g.C = ws + o_y; g.bias = bias ? (const float*)(ws + o_b) : nullptr; g.R = r ? (const float*)(ws + o_r) : nullptr;
+  }
+  if (const char* e = mia_gemm_check(g)) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
+  if (mia_gemm_launch(g, dtype, ctx->stream) != 0) return mia_fail(ctx, MIA_ERR_DEVICE, "op_linear: launch failed");
+  if (mem == MIA_MEM_HOST) {
+    MIA_HIP(ctx, hipMemcpyAsync(y, g.C, yb, hipMemcpyDeviceToHost, ctx->stream));
+    MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return MIA_OK;
+}

@@ -4,11 +4,15 @@
 // (MultiHeadAttention.swift:49-59).  Launch sequence per layer: LN -> fused QKV GEMM (V transposed in the
 // epilogue) -> flash attention -> out-proj GEMM (+bias +residual, fp32) -> LN -> MLP1 GEMM (+bias, erf-GELU)
 // -> MLP2 GEMM (+bias +residual).  The two convolutions are GEMMs over overlapping row windows (gemm.hip).
+#include <cstdlib>
+
 #include "whisper.h"
 
 namespace {
 
-int gemm(mia_whisper* w, const GemmArgs& g, int cls = MIA_PROF_ENC_GEMM) {
+int gemm(mia_whisper* w, GemmArgs g, int cls = MIA_PROF_ENC_GEMM) {
+  static const int forced = getenv("MIA_GEMM_VARIANT") ? atoi(getenv("MIA_GEMM_VARIANT")) : -1;
+  if (forced >= 0) g.variant = forced;
   if (const char* e = mia_gemm_check(g)) return mia_fail(w->ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
   const int rec = mia_prof_begin(w->ctx, cls, 2.0 * g.M * (double)g.N * g.K * (g.batch > 0 ? g.batch : 1));
   const int rc = mia_gemm_launch(g, w->dtype, w->ctx->stream);
