@@ -28,6 +28,7 @@ extern "C" {
 
 typedef struct mia_ctx mia_ctx;
 typedef struct mia_whisper mia_whisper;
+typedef struct mia_codec mia_codec;
 
 typedef enum {
   MIA_OK = 0,
@@ -171,6 +172,40 @@ int mia_whisper_detect_language(mia_whisper* w, int32_t sot, int32_t n_languages
 int mia_whisper_transcribe_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right,
                                    const mia_decode_opts* opts, int32_t* tokens, int32_t* n_tokens, float* avg_logprob,
                                    float* no_speech_prob, int mem);
+
+/* ---- neural codec decoders (fp32, like the reference) ------------------------------------------ */
+/* SNACConfig (TTS/Orpheus/SNAC/SNACConfig.swift:9-94); tensors use the checkpoint key schema the reference loads
+ * (decoder.model.layers.N..., quantizer.quantizers.i.{codebook.weight,out_proj.{weight_g,weight_v,bias}};
+ * SNACDecoder.swift:101-243,358-368), float32. */
+typedef struct {
+  int32_t latent_dim, decoder_dim;
+  int32_t n_rates; int32_t decoder_rates[8];
+  int32_t n_vq; int32_t vq_strides[4];
+  int32_t codebook_size, codebook_dim;
+  int32_t noise, depthwise;
+} mia_snac_config;
+/* DACConfig (Codec/DAC/DACModel.swift:169-203): decoder side only. */
+typedef struct {
+  int32_t latent_dim, decoder_dim;
+  int32_t n_rates; int32_t decoder_rates[8];
+  int32_t n_codebooks, codebook_size, codebook_dim;
+} mia_dac_config;
+
+mia_codec* mia_snac_load(mia_ctx* ctx, const mia_snac_config* cfg, const mia_tensor_view* tensors, int n_tensors);
+mia_codec* mia_dac_load(mia_ctx* ctx, const mia_dac_config* cfg, const mia_tensor_view* tensors, int n_tensors);
+void mia_codec_free(mia_codec* c);
+/* Samples produced / Gaussian values consumed for a latent of `latent_len` steps (SNAC: max_i n_i*vq_stride_i; DAC: T). */
+int64_t mia_codec_output_len(mia_codec* c, int64_t latent_len);
+int64_t mia_codec_noise_len(mia_codec* c, int64_t latent_len);
+/* Replaces SNACDecoder.decode(codes:) (TTS/Orpheus/SNAC/SNACDecoder.swift:281-289, called at
+ * TTS/Orpheus/TTSEngine/OrpheusTTS.swift:361).  codes[i] -> n_codes[i] ids of VQ level i.  `noise`: the N(0,1) draws of
+ * the NoiseBlocks (NoiseBlock.swift:33), block after block, mia_codec_noise_len() values in total, or NULL for none.
+ * pcm: float32 mono 24 kHz. */
+int mia_snac_decode(mia_codec* c, const int32_t* const* codes, const int32_t* n_codes, int n_levels, const float* noise,
+                    int64_t n_noise, float* pcm, int64_t pcm_capacity, int64_t* n_samples, int mem);
+/* Replaces DACCodec.decodeFromCodes (Codec/DAC/DACModel.swift:303-306) for one sequence: codes int32 [n_codebooks][T]. */
+int mia_dac_decode(mia_codec* c, const int32_t* codes, int n_codebooks, int64_t T, float* pcm, int64_t pcm_capacity,
+                   int64_t* n_samples, int mem);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,39 @@
+// codec.h -- internal interface of the fp32 codec-decoder kernels (codec_kernels.hip) and the layer programs (codec.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mia.h"
+
+// Tap-structured fp32 GEMM: Y[row(m)][n] = epi( sum_{tap,c} pre(X[m + tap*dil - pad][c]) * W[n][tap*Cin + c] + bias[n] )
+//   row(m) = m*y_row_mul + y_row_off + z*y_phase_step (rows outside [0,T_out) are dropped); z = grid.z phase, W += z*w_phase_stride
+struct ConvGemmArgs {
+  const float* X = nullptr; int64_t ldx = 0; int T_in = 0;
+  const float* W = nullptr; int64_t w_phase_stride = 0;
+  const float* bias = nullptr;
+  const float* alpha = nullptr;        // snake prologue on X (per input channel), or null
+  float* Y = nullptr; int64_t ldy = 0; int T_out = 0;
+  int y_row_mul = 1, y_row_off = 0, y_phase_step = 0;
+  const float* R = nullptr; int64_t ldr = 0;   // residual (same row mapping as Y)
+  const float* noise = nullptr;        // if set: Y = R + noise[row] * (acc + bias)
+  int M = 0, N = 0, Cin = 0, taps = 1, dil = 1, pad = 0;
+  int tanh_out = 0;
+};
+
+constexpr int MIA_MAX_LEVELS = 4;
+struct EmbedArgs {
+  const int32_t* codes[MIA_MAX_LEVELS];   // device, null = level absent
+  const float* codebook[MIA_MAX_LEVELS];  // [size][cb_dim]
+  const float* weff[MIA_MAX_LEVELS];      // folded weight-normed out_proj [C][cb_dim]
+  const float* bias[MIA_MAX_LEVELS];      // [C]
+  int stride[MIA_MAX_LEVELS];
+  int n_levels, cb_dim;
+};
+
+const char* codec_conv_gemm_check(const ConvGemmArgs& g);
+int codec_conv_gemm_launch(const ConvGemmArgs& g, int phases, hipStream_t s);
+int codec_dwconv_launch(const float* x, float* y, const float* w, const float* bias, const float* a_pre, const float* a_post, int T, int C,
+                        int K, int dil, hipStream_t s);
+int codec_conv_out1_launch(const float* x, float* out, const float* w, const float* bias, const float* alpha, int T, int C, int K, hipStream_t s);
+int codec_embed_launch(const EmbedArgs& a, float* z, int T, int C, hipStream_t s);
+int codec_noise1_launch(float* x, const float* w, const float* noise, int T, int C, hipStream_t s);

@@ -1,0 +1,286 @@
+// codec_kernels.hip -- fp32 kernels of the neural-codec decoders (SNAC, DAC) on gfx950.
+//
+// Activations are channels-last, time-major fp32 [T][C] throughout (the reference hops between [B,C,T] and [B,T,C] at
+// every layer, SNACDecoder.swift:265-270, ResidualUnit.swift:62-78; here nothing is ever transposed).
+//
+//  * conv_gemm_f32   every dense convolution / transposed convolution / 1x1 projection as ONE tap-structured GEMM on the
+//                    exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32): A(m, tap, c) = pre(X[m + tap*dil - pad][c]) with an
+//                    optional snake prologue x + sin^2(a x)/(a + 1e-9) applied while staging A into LDS; a transposed
+//                    convolution with kernel 2*stride is `stride` such GEMMs (grid.z = output phase) over two-row windows,
+//                    writing every `stride`-th output row -- no zero-stuffing, no scatter-add.
+//                    Epilogue: bias, optional residual add, optional noise modulation r + noise[t]*acc, optional tanh.
+//  * dwconv_snake    depthwise k-tap dilated conv with snake before and after (SNAC residual unit head), HBM-bound.
+//  * conv_out1       snake -> conv k (C -> 1) -> tanh output stage.
+//  * embed_codes     codebook gather + folded weight-normed 1x1 out_proj + stride expansion + level sum.
+//  * noise_mod1      x[t][:] += noise[t] * (x[t][:] . w)   (SNAC NoiseBlock with one modulation channel).
+#include "codec.h"
+#include "mia_device.h"
+
+namespace {
+
+__device__ __forceinline__ float snake_f(float x, float a, float ra) {
+  const float s = __sinf(a * x);
+  return x + ra * (s * s);
+}
+// full-precision variant used where the argument can be large
+__device__ __forceinline__ float snake_p(float x, float a, float ra) {
+  const float s = sinf(a * x);
+  return x + ra * (s * s);
+}
+
+constexpr int GBM = 128, GBK = 32, GSTR = GBK + 1;   // LDS row stride 33 floats: conflict-free column reads
+
+// WN = 32-column MFMA tiles per wave along N (2 -> 128-wide block tile, 1 -> 64-wide)
+template <int WN>
+__global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
+  constexpr int GBN = 64 * WN;
+  __shared__ float As[GBM * GSTR];
+  __shared__ float Bs[GBN * GSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
+  const int z = blockIdx.z;
+  const float* __restrict__ W = g.W + (int64_t)z * g.w_phase_stride;
+  const int Ktot = g.taps * g.Cin;
+
+  // staging coordinates: A: 4 rows x float4 per thread, B: WN*2 rows x float4 per thread
+  const int s_row = tid >> 3, s_col = (tid & 7) * 4;
+  float4 ra[4], rb[2 * WN];
+  auto load_tiles = [&](int k0) {
+    const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin + s_col;
+    float al[4] = {0.f, 0.f, 0.f, 0.f}, ral[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.alpha) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { al[j] = g.alpha[c0 + j]; ral[j] = 1.0f / (al[j] + 1e-9f); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + s_row + 32 * i;
+      const int64_t xr = (int64_t)m + (int64_t)tap * g.dil - g.pad;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < g.M && xr >= 0 && xr < g.T_in) {
+        v = *reinterpret_cast<const float4*>(g.X + xr * g.ldx + c0);
+        if (g.alpha) {
+          v.x = snake_p(v.x, al[0], ral[0]); v.y = snake_p(v.y, al[1], ral[1]);
+          v.z = snake_p(v.z, al[2], ral[2]); v.w = snake_p(v.w, al[3], ral[3]);
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * WN; ++i) {
+      const int n = n0 + s_row + 32 * i;
+      rb[i] = n < g.N ? *reinterpret_cast<const float4*>(W + (int64_t)n * Ktot + k0 + s_col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* d = As + (s_row + 32 * i) * GSTR + s_col;
+      d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * WN; ++i) {
+      float* d = Bs + (s_row + 32 * i) * GSTR + s_col;
+      d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
+    }
+  };
+
+  f32x16 acc[2][WN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int a_off = (wr * 64 + (lane & 31)) * GSTR + (lane >> 5);
+  const int b_off = (wc * 32 * WN + (lane & 31)) * GSTR + (lane >> 5);
+  const int nk = Ktot / GBK;
+  load_tiles(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                       // previous tile fully consumed
+    store_tiles();
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles((kt + 1) * GBK);   // global loads fly under the MFMAs below
+#pragma unroll 4
+    for (int kk = 0; kk < GBK; kk += 2) {
+      float a[2], b[WN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[a_off + i * 32 * GSTR + kk];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = Bs[b_off + j * 32 * GSTR + kk];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // epilogue: lane owns column n = ..+(lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = n0 + wc * 32 * WN + j * 32 + (lane & 31);
+    if (n >= g.N) continue;
+    const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= g.M) continue;
+        const int64_t yr = (int64_t)m * g.y_row_mul + g.y_row_off + (int64_t)z * g.y_phase_step;
+        if (yr < 0 || yr >= g.T_out) continue;
+        float v = acc[i][j][r] + bias;
+        if (g.noise) v = g.R[yr * g.ldr + n] + g.noise[yr] * v;
+        else if (g.R) v += g.R[yr * g.ldr + n];
+        if (g.tanh_out) v = tanhf(v);
+        g.Y[yr * g.ldy + n] = v;
+      }
+  }
+}
+
+// y[t][c] = post( bias[c] + sum_k w[k][c] * pre(x[t + (k - K/2)*dil][c]) ),  pre/post = snake with alpha_pre/alpha_post (optional)
+__global__ __launch_bounds__(256) void dwconv_snake(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, const float* __restrict__ a_pre,
+                                                    const float* __restrict__ a_post, int T, int C, int K, int dil) {
+  const int c4n = C >> 2;
+  const int64_t total = (int64_t)T * c4n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int t = (int)(e / c4n), c = (int)(e - (int64_t)t * c4n) * 4;
+    float ap[4] = {0, 0, 0, 0}, rap[4] = {0, 0, 0, 0};
+    if (a_pre) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ap[j] = a_pre[c + j]; rap[j] = 1.0f / (ap[j] + 1e-9f); }
+    }
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = bias ? bias[c + j] : 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int ts = t + (k - K / 2) * dil;
+      if (ts < 0 || ts >= T) continue;
+      const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)ts * C + c);
+      const float4 wk = *reinterpret_cast<const float4*>(w + (int64_t)k * C + c);
+      float xv[4] = {v.x, v.y, v.z, v.w};
+      const float wv[4] = {wk.x, wk.y, wk.z, wk.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (a_pre) xv[j] = snake_p(xv[j], ap[j], rap[j]);
+        acc[j] = fmaf(wv[j], xv[j], acc[j]);
+      }
+    }
+    if (a_post) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float a = a_post[c + j]; acc[j] = snake_p(acc[j], a, 1.0f / (a + 1e-9f)); }
+    }
+    *reinterpret_cast<float4*>(y + (int64_t)t * C + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+// out[t] = tanh( bias + sum_{k,c} w[k*C + c] * snake(x[t + k - K/2][c]) )      (C -> 1 output convolution)
+__global__ __launch_bounds__(256) void conv_out1(const float* __restrict__ x, float* __restrict__ out, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, const float* __restrict__ alpha, int T, int C, int K) {
+  extern __shared__ float sm[];        // w[K*C] | alpha[C] | ralpha[C]
+  float* sw = sm;
+  float* sa = sm + K * C;
+  float* sr = sa + C;
+  for (int i = threadIdx.x; i < K * C; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += 256) { const float a = alpha ? alpha[i] : 0.f; sa[i] = a; sr[i] = 1.0f / (a + 1e-9f); }
+  __syncthreads();
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float acc = bias ? bias[0] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int ts = t + k - K / 2;
+    if (ts < 0 || ts >= T) continue;
+    const float* xr = x + (int64_t)ts * C;
+    for (int c = 0; c < C; c += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s = alpha ? snake_p(xv[j], sa[c + j], sr[c + j]) : xv[j];
+        acc = fmaf(sw[k * C + c + j], s, acc);
+      }
+    }
+  }
+  out[t] = tanhf(acc);
+}
+
+// z[t][ch] = sum_levels ( b_l[ch] + sum_j cb_l[code_l[t / stride_l]][j] * Weff_l[ch][j] )
+__global__ __launch_bounds__(256) void embed_codes(EmbedArgs a, float* __restrict__ z, int T, int C) {
+  const int64_t total = (int64_t)T * C;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int t = (int)(e / C), ch = (int)(e - (int64_t)t * C);
+    float acc = 0.f;
+    for (int l = 0; l < a.n_levels; ++l) {
+      if (!a.codes[l]) continue;
+      const int code = a.codes[l][t / a.stride[l]];
+      const float* cb = a.codebook[l] + (int64_t)code * a.cb_dim;
+      const float* wv = a.weff[l] + (int64_t)ch * a.cb_dim;
+      float s = 0.f;
+      for (int j = 0; j < a.cb_dim; ++j) s = fmaf(cb[j], wv[j], s);
+      acc += s + a.bias[l][ch];
+    }
+    z[e] = acc;
+  }
+}
+
+// x[t][:] += noise[t] * dot(x[t][:], w)      one wave per row
+__global__ __launch_bounds__(256) void noise_mod1(float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ noise, int T, int C) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= T) return;
+  float* xr = x + (int64_t)t * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s = fmaf(xr[c], w[c], s);
+  s = wave_sum(s) * noise[t];
+  for (int c = lane; c < C; c += 64) xr[c] += s;
+}
+
+}  // namespace
+
+const char* codec_conv_gemm_check(const ConvGemmArgs& g) {
+  if (g.M <= 0 || g.N <= 0 || g.Cin <= 0 || g.taps <= 0) return "conv_gemm: bad shape";
+  if (g.Cin % GBK) return "conv_gemm: Cin must be a multiple of 32";
+  if (g.ldx % 4 || ((uintptr_t)g.X & 15) || ((uintptr_t)g.W & 15)) return "conv_gemm: X rows / W must be 16-byte aligned";
+  if (g.noise && !g.R) return "conv_gemm: noise modulation needs the residual input";
+  return nullptr;
+}
+
+int codec_conv_gemm_launch(const ConvGemmArgs& g, int phases, hipStream_t s) {
+  if (g.N > 64) {
+    dim3 grid((g.M + GBM - 1) / GBM, (g.N + 127) / 128, phases);
+    hipLaunchKernelGGL(conv_gemm_f32<2>, grid, dim3(256), 0, s, g);
+  } else {
+    dim3 grid((g.M + GBM - 1) / GBM, (g.N + 63) / 64, phases);
+    hipLaunchKernelGGL(conv_gemm_f32<1>, grid, dim3(256), 0, s, g);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int codec_dwconv_launch(const float* x, float* y, const float* w, const float* bias, const float* a_pre, const float* a_post, int T, int C,
+                        int K, int dil, hipStream_t s) {
+  if (C % 4) return -1;
+  const int64_t total = (int64_t)T * (C / 4);
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(dwconv_snake, dim3(grid), dim3(256), 0, s, x, y, w, bias, a_pre, a_post, T, C, K, dil);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int codec_conv_out1_launch(const float* x, float* out, const float* w, const float* bias, const float* alpha, int T, int C, int K, hipStream_t s) {
+  if (C % 4) return -1;
+  const size_t lds = (size_t)(K * C + 2 * C) * 4;
+  hipLaunchKernelGGL(conv_out1, dim3((T + 255) / 256), dim3(256), lds, s, x, out, w, bias, alpha, T, C, K);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int codec_embed_launch(const EmbedArgs& a, float* z, int T, int C, hipStream_t s) {
+  const int64_t total = (int64_t)T * C;
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(embed_codes, dim3(grid), dim3(256), 0, s, a, z, T, C);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int codec_noise1_launch(float* x, const float* w, const float* noise, int T, int C, hipStream_t s) {
+  hipLaunchKernelGGL(noise_mod1, dim3((T + 3) / 4), dim3(256), 0, s, x, w, noise, T, C);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -140,3 +140,131 @@ def synth_clip(i: int, n_samples: int = 480000) -> np.ndarray:
     t = np.arange(n_samples, dtype=np.float64) / SAMPLE_RATE
     x = 0.1 * rng.standard_normal(n_samples) + 0.2 * np.sin(2 * np.pi * (220.0 * (1 + i % 8)) * t)
     return np.clip(x, -1.0, 1.0).astype(np.float32)
+
+
+# ---- neural codecs (SNAC 24 kHz, DAC speech 24 kHz) -------------------------------------------------------------
+@dataclass
+class SNACConfig:
+    """SNACConfig.swift:9-94 defaults == mlx-community/snac_24khz."""
+    latent_dim: int = 768
+    decoder_dim: int = 1024
+    decoder_rates: tuple = (8, 8, 4, 2)
+    vq_strides: tuple = (4, 2, 1)
+    codebook_size: int = 4096
+    codebook_dim: int = 8
+    noise: bool = True
+    depthwise: bool = True
+    noise_channels: int = 1      # NoiseBlock.swift:18-24 builds 1 output channel; upstream checkpoints carry dim -> dim
+
+
+@dataclass
+class DACConfig:
+    """DACConfig.speechDefault (DACModel.swift:192-202), decoder side; latent = encoder_dim * 2^len(rates) = 1024."""
+    latent_dim: int = 1024
+    decoder_dim: int = 1536
+    decoder_rates: tuple = (8, 5, 4, 2)
+    n_codebooks: int = 2
+    codebook_size: int = 1024
+    codebook_dim: int = 8
+
+
+SNAC_CONFIGS = {"snac_24khz": SNACConfig(), "snac_micro": SNACConfig(64, 128, (4, 2), (2, 1), 64, 8), "snac_micro_cn": SNACConfig(64, 128, (4, 2), (2, 1), 64, 8, noise_channels=-1)}
+DAC_CONFIGS = {"dac_speech": DACConfig(), "dac_micro": DACConfig(64, 128, (4, 5), 2, 64, 8)}
+
+
+def _wn_pair(rng, shape, norm_axes, g_shape):
+    """A (weight_g, weight_v) pair as a checkpoint stores them: v arbitrary, g ~ the norm of a LeCun-scaled weight."""
+    fan_in = int(np.prod([shape[a] for a in norm_axes]))
+    v = rng.standard_normal(shape, dtype=np.float32) / np.float32(math.sqrt(max(fan_in, 1)))
+    g = (np.float32(1.0) + np.float32(0.1) * rng.standard_normal(g_shape, dtype=np.float32)).astype(np.float32)
+    return g, v.astype(np.float32)
+
+
+def snac_weights(cfg: SNACConfig, seed: int = 0) -> dict[str, np.ndarray]:
+    """Random-init SNAC decoder + quantizer tensors in the checkpoint key schema (SNACDecoder.swift:101-243,358-368)."""
+    w: dict[str, np.ndarray] = {}
+    rng = np.random.Generator(np.random.PCG64(seed + 77))
+    P = "decoder.model.layers."
+
+    def conv(p, cout, k, cin_g, bias=True):
+        g, v = _wn_pair(rng, (cout, k, cin_g), (1, 2), (cout, 1, 1))
+        w[p + ".weight_g"], w[p + ".weight_v"] = g, v
+        if bias:
+            w[p + ".bias"] = (0.05 * rng.standard_normal(cout)).astype(np.float32)
+
+    def alpha(p, c):
+        w[p] = (1.0 + 0.2 * rng.standard_normal((1, c, 1))).astype(np.float32).clip(0.3, 2.0)
+
+    for i in range(len(cfg.vq_strides)):
+        q = f"quantizer.quantizers.{i}"
+        w[q + ".codebook.weight"] = rng.standard_normal((cfg.codebook_size, cfg.codebook_dim), dtype=np.float32)
+        g, v = _wn_pair(rng, (cfg.latent_dim, 1, cfg.codebook_dim), (1, 2), (cfg.latent_dim, 1, 1))
+        w[q + ".out_proj.weight_g"], w[q + ".out_proj.weight_v"] = g, v
+        w[q + ".out_proj.bias"] = (0.05 * rng.standard_normal(cfg.latent_dim)).astype(np.float32)
+    conv(P + "0", cfg.latent_dim, 7, 1)
+    conv(P + "1", cfg.decoder_dim, 1, cfg.latent_dim)
+    cin = cfg.decoder_dim
+    for i, s in enumerate(cfg.decoder_rates):
+        cout = cfg.decoder_dim >> (i + 1)
+        b = f"{P}{2 + i}.block.layers."
+        alpha(b + "0.alpha", cin)
+        g, v = _wn_pair(rng, (cin, 2 * s, cout), (1, 2), (cin, 1, 1))
+        w[b + "1.weight_g"], w[b + "1.weight_v"] = g, v
+        w[b + "1.bias"] = (0.05 * rng.standard_normal(cout)).astype(np.float32)
+        ru = 2
+        if cfg.noise:
+            cn = cout if cfg.noise_channels < 0 else cfg.noise_channels
+            g, v = _wn_pair(rng, (cn, 1, cout), (1, 2), (cn, 1, 1))
+            w[b + "2.linear.weight_g"], w[b + "2.linear.weight_v"] = g, v
+            ru = 3
+        for r in range(3):
+            u = f"{b}{ru + r}.block.layers."
+            alpha(u + "0.alpha", cout)
+            conv(u[:-1] + ".1", cout, 7, 1)
+            alpha(u + "2.alpha", cout)
+            conv(u[:-1] + ".3", cout, 1, cout)
+        cin = cout
+    n = len(cfg.decoder_rates)
+    alpha(f"{P}{2 + n}.alpha", cin)
+    conv(f"{P}{3 + n}", 1, 7, cin)
+    return w
+
+
+def dac_weights(cfg: DACConfig, seed: int = 0) -> dict[str, np.ndarray]:
+    """Random-init DAC decoder + quantizer tensors with the reference's Module key paths (DACModel.swift:120-164, DACLayers.swift)."""
+    w: dict[str, np.ndarray] = {}
+    rng = np.random.Generator(np.random.PCG64(seed + 99))
+    P = "decoder.model.layers."
+
+    def conv(p, cout, k, cin):
+        g, v = _wn_pair(rng, (cout, k, cin), (1, 2), (cout, 1, 1))
+        w[p + ".weight_g"], w[p + ".weight_v"] = g, v
+        w[p + ".bias"] = (0.05 * rng.standard_normal(cout)).astype(np.float32)
+
+    def alpha(p, c):
+        w[p] = (1.0 + 0.2 * rng.standard_normal((1, 1, c))).astype(np.float32).clip(0.3, 2.0)
+
+    for i in range(cfg.n_codebooks):
+        q = f"quantizer.quantizers.{i}"
+        w[q + ".codebook.weight"] = rng.standard_normal((cfg.codebook_size, cfg.codebook_dim), dtype=np.float32)
+        conv(q + ".out_proj", cfg.latent_dim, 1, cfg.codebook_dim)
+    conv(P + "0", cfg.decoder_dim, 7, cfg.latent_dim)
+    cin = cfg.decoder_dim
+    for i, s in enumerate(cfg.decoder_rates):
+        cout = cfg.decoder_dim >> (i + 1)
+        b = f"{P}{1 + i}.block.layers."
+        alpha(b + "0.alpha", cin)
+        g, v = _wn_pair(rng, (cout, 2 * s, cin), (0, 1), (1, 1, cin))      # normalised per INPUT channel (exceptDim 2)
+        w[b + "1.weight_g"], w[b + "1.weight_v"] = g, v
+        w[b + "1.bias"] = (0.05 * rng.standard_normal(cout)).astype(np.float32)
+        for r in range(3):
+            u = f"{b}{2 + r}.block.layers."
+            alpha(u + "0.alpha", cout)
+            conv(u[:-1] + ".1", cout, 7, cout)
+            alpha(u + "2.alpha", cout)
+            conv(u[:-1] + ".3", cout, 1, cout)
+        cin = cout
+    n = len(cfg.decoder_rates)
+    alpha(f"{P}{1 + n}.alpha", cin)
+    conv(f"{P}{2 + n}", 1, 7, cin)
+    return w
