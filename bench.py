@@ -65,6 +65,69 @@ def cpu_baseline(dims_name: str, seed: int, n_threads: int, max_new_tokens: int)
                        f"{n_tok} greedy steps {t3 - t2:.2f}s scaled to {full_tokens} steps")}
 
 
+def codec_bench(ctx, torch):
+    """Second half of BASELINE.json's metric ("codec samples/s"): SNAC 24 kHz decode of one Orpheus chunk (1200 tokens ->
+    171 frames -> 350 208 samples) and DAC speech decode of 10 s (750 code steps), random-init weights,
+    codes/noise resident on the host side of the ABI excluded: timed with device-resident inputs via HIP events."""
+    import ctypes as C
+    from mlx_swift_audio_amd import codec as HC
+    from mlx_swift_audio_amd import synthetic as S
+    res = {}
+    rng = np.random.default_rng(7)
+    # ---- SNAC
+    cfg = S.SNAC_CONFIGS["snac_24khz"]
+    dec = HC.SNACDecoder.load(ctx, cfg, S.snac_weights(cfg, 0))
+    N = 171
+    codes = [torch.from_numpy(rng.integers(0, cfg.codebook_size, N * (4 // s)).astype(np.int32)).cuda() for s in cfg.vq_strides]
+    T0 = N * 4
+    n_noise, n_out = dec.noise_len(T0), dec.output_len(T0)
+    noise = torch.randn(n_noise, device="cuda")
+    pcm = torch.empty(n_out, device="cuda")
+    ptrs = (C.c_void_p * 3)(*[c.data_ptr() for c in codes])
+    n_codes = np.asarray([c.numel() for c in codes], np.int32)
+    ns = C.c_int64(0)
+
+    def run_snac():
+        ctx.check(ctx.lib.mia_snac_decode(dec.h, ptrs, n_codes.ctypes.data, 3, noise.data_ptr(), n_noise, pcm.data_ptr(), n_out, C.byref(ns), 1))
+
+    for _ in range(2):
+        run_snac()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        run_snac()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    res["snac_24khz_decode"] = {"samples_per_s": round(n_out / (ms * 1e-3), 0), "ms": round(ms, 3), "samples": n_out,
+                                "realtime_factor": round(n_out / 24000.0 / (ms * 1e-3), 1)}
+    dec.close()
+    # ---- DAC
+    dcfg = S.DAC_CONFIGS["dac_speech"]
+    dd = HC.DACCodec.load(ctx, dcfg, S.dac_weights(dcfg, 0))
+    T = 750
+    dcodes = torch.from_numpy(rng.integers(0, dcfg.codebook_size, (dcfg.n_codebooks, T)).astype(np.int32)).cuda()
+    d_out = dd.output_len(T)
+    dpcm = torch.empty(d_out, device="cuda")
+
+    def run_dac():
+        ctx.check(ctx.lib.mia_dac_decode(dd.h, dcodes.data_ptr(), dcfg.n_codebooks, T, dpcm.data_ptr(), d_out, C.byref(ns), 1))
+
+    for _ in range(2):
+        run_dac()
+    e0.record()
+    for _ in range(reps):
+        run_dac()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    res["dac_speech_decode"] = {"samples_per_s": round(d_out / (ms * 1e-3), 0), "ms": round(ms, 3), "samples": d_out,
+                                "realtime_factor": round(d_out / 24000.0 / (ms * 1e-3), 1)}
+    dd.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +138,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--max-new-tokens", type=int, default=0, help="cap generated tokens per clip (0 = full 448 budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-codec", action="store_true", help="skip the SNAC/DAC decode samples/s side measurement")
     ap.add_argument("--cpu-tokens", type=int, default=24, help="greedy steps actually run by the CPU baseline")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -194,6 +258,8 @@ def main():
                    "realtime_factor": round(value, 1)},
         "roofline": roofline, "stages": stage,
     }
+    if rank == 0 and not args.no_codec:
+        out["codec"] = codec_bench(ctx, torch)
     if rank == 0 and not args.no_cpu_baseline:
         try:
             ncpu = min(16, len(os.sched_getaffinity(0)))   # the GPU box's CPU share for one GPU is 16 cores

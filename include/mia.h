@@ -29,6 +29,7 @@ extern "C" {
 typedef struct mia_ctx mia_ctx;
 typedef struct mia_whisper mia_whisper;
 typedef struct mia_codec mia_codec;
+typedef struct mia_lm mia_lm;
 
 typedef enum {
   MIA_OK = 0,
@@ -206,6 +207,44 @@ int mia_snac_decode(mia_codec* c, const int32_t* const* codes, const int32_t* n_
 /* Replaces DACCodec.decodeFromCodes (Codec/DAC/DACModel.swift:303-306) for one sequence: codes int32 [n_codebooks][T]. */
 int mia_dac_decode(mia_codec* c, const int32_t* codes, int n_codebooks, int64_t T, float* pcm, int64_t pcm_capacity,
                    int64_t* n_samples, int mem);
+
+/* ---- autoregressive LMs (Llama-3 / Qwen2 blocks) ------------------------------------------------ */
+/* OrpheusConfig (TTS/Orpheus/BuildingBlocks/TransformerBlock.swift:16-34) / Qwen2Config (TTS/CosyVoice2/LLM/Qwen2LM.swift:15-43).
+ * Tensors use the Hugging Face key schema both ports load: model.embed_tokens.weight, model.layers.N.self_attn.{q,k,v,o}_proj.weight
+ * (+ .bias for q,k,v when qkv_bias), model.layers.N.mlp.{gate,up,down}_proj.weight, model.layers.N.{input,post_attention}_layernorm.weight,
+ * model.norm.weight, lm_head.weight (absent when tie_embeddings). */
+typedef struct {
+  int32_t vocab, hidden, inter, n_layers, n_heads, n_kv_heads, head_dim, max_ctx;
+  float rms_eps, rope_theta;
+  int32_t rope_llama3;            /* 1: Llama3RoPE frequency scaling (TTS/Shared/Llama3RoPE.swift:27-66) */
+  float rope_factor, rope_low, rope_high;
+  int32_t rope_old_ctx;
+  int32_t qkv_bias, tie_embeddings;
+} mia_lm_config;
+
+/* sampleNextToken parameters (TTS/Orpheus/TTSEngine/OrpheusTTS.swift:375-470): repetition penalty over the last
+ * rep_window generated ids -> /temperature -> top-p (keeps the first token crossing p) -> categorical. */
+typedef struct {
+  float temperature, top_p, rep_penalty;
+  int32_t rep_window, max_new_tokens;
+  int32_t n_stop; int32_t stop_ids[4];
+  int32_t reserved;
+} mia_lm_sampler;
+
+mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia_tensor_view* tensors, int n_tensors, int dtype);
+void mia_lm_free(mia_lm* lm);
+int mia_lm_reset(mia_lm* lm);
+/* model(ids, cache) then logits[0,-1] (OrpheusTTS.swift:245-251,289): appends n ids to the KV cache, returns the fp32
+ * logits after the last one into last_logits [vocab] (host pointer, may be NULL). */
+int mia_lm_forward(mia_lm* lm, const int32_t* ids, int n, float* last_logits);
+/* The whole sampling loop of generateChunk (OrpheusTTS.swift:245-348) on device: prompt, then up to max_new_tokens sampled
+ * ids (stops after emitting a stop id).  uniforms: max_new_tokens values in [0,1), one per draw (explicit RNG: inverse CDF
+ * over the kept tokens in index order).  Host pointers. */
+int mia_lm_generate(mia_lm* lm, const int32_t* prompt, int n_prompt, const mia_lm_sampler* sampler, const float* uniforms,
+                    int32_t* out_tokens, int32_t* n_out);
+/* One sampleNextToken call on caller-provided logits (host pointers). */
+int mia_sample_top_p(mia_ctx* ctx, const float* logits, int V, const int32_t* history, int n_hist, float rep_penalty,
+                     float temperature, float top_p, float uniform, int32_t* out);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,7 @@
 #pragma once
 #include "whisper.h"
 
-enum { SK_OUT16 = 0, SK_OUTF32 = 1, SK_PARTIAL = 2, SK_QKV = 3 };
+enum { SK_OUT16 = 0, SK_OUTF32 = 1, SK_PARTIAL = 2, SK_QKV = 3, SK_SWIGLU = 4 };
 
 struct SkinnyArgs {
   const uint16_t* A; int64_t lda;        // [M][K]
@@ -17,6 +17,8 @@ struct SkinnyArgs {
 int dec_launch_embed_ln(mia_whisper* w, const LNW& ln, hipStream_t s);
 int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln, hipStream_t s);
 int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s);
+// model-independent form (dtype = MIA_BF16 | MIA_F16); SK_SWIGLU: W rows interleaved gate/up, out[m][n/2] = silu(g)*u (16-bit)
+int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s);
 int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const void* vc, void* out, int fixed_keys, int cap_keys,
                          hipStream_t s);
 int dec_launch_head(mia_whisper* w, int32_t* last_ts, const DecodeParams& p, hipStream_t s);

@@ -213,6 +213,14 @@ __global__ __launch_bounds__(64) void dec_skinny_gemm(SkinnyArgs a) {
           continue;
         }
         if (a.bias) v += a.bias[n + j];
+        if (MODE == SK_SWIGLU) {   // interleaved rows: even column = gate, odd column = up
+          if (j & 1) continue;
+          float u = av[j + 1];
+          if (a.bias) u += a.bias[n + j + 1];
+          const float sg = v / (1.0f + __expf(-v));
+          reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + ((n + j) >> 1)] = T::from_f32(sg * u);
+          continue;
+        }
         if (a.act == MIA_ACT_GELU) v = gelu_erf(v);
         if (MODE == SK_OUTF32) reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n + j] = v;
         else if (MODE == SK_OUT16) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + n + j] = T::from_f32(v);
@@ -554,15 +562,19 @@ static void skinny_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
   switch (mode) {
     case SK_OUT16: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_OUT16, 1, 4>), grid, block, 0, s, a); break;
     case SK_PARTIAL: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_PARTIAL, 1, 4>), grid, block, 0, s, a); break;
+    case SK_SWIGLU: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_SWIGLU, 1, 4>), grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_QKV, 1, 4>), grid, block, 0, s, a); break;
   }
 }
 
-int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s) {
+int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) {
   if (a.K % (32 * a.S) != 0 || a.lda % 8 != 0) return -1;
-  if (w->dtype == MIA_F16) skinny_launch_t<F16>(a, mode, s); else skinny_launch_t<BF16>(a, mode, s);
+  if (mode == SK_SWIGLU && (a.N & 3)) return -1;
+  if (dtype == MIA_F16) skinny_launch_t<F16>(a, mode, s); else skinny_launch_t<BF16>(a, mode, s);
   return 0;
 }
+
+int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s) { return skinny_gemm_launch(a, mode, w->dtype, s); }
 
 int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const void* vc, void* out, int fixed_keys, int cap_keys,
                          hipStream_t s) {

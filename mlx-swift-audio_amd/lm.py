@@ -1,0 +1,131 @@
+"""Host-side mirror of the reference's causal-LM interface (OrpheusLMHeadModel / Qwen2 blocks + sampleNextToken + parseOutput),
+backed by the gfx950 HIP layer (include/mia.h).  parse_output is integer bookkeeping and stays on the host, as in the Swift."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .whisper import _TensorView
+
+END_TOKEN = 128258                    # OrpheusTTS.swift:75-85
+CODE_OFFSET = 128266
+AUDIO_CODE_DATA_START_MARKER = 128257
+MAX_TOKEN_COUNT = 1200
+REPETITION_CONTEXT_SIZE = 20
+
+
+class _LmCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab", "hidden", "inter", "n_layers", "n_heads", "n_kv_heads", "head_dim", "max_ctx")] + \
+               [("rms_eps", C.c_float), ("rope_theta", C.c_float), ("rope_llama3", C.c_int32), ("rope_factor", C.c_float),
+                ("rope_low", C.c_float), ("rope_high", C.c_float), ("rope_old_ctx", C.c_int32), ("qkv_bias", C.c_int32),
+                ("tie_embeddings", C.c_int32)]
+
+
+class _Sampler(C.Structure):
+    _fields_ = [("temperature", C.c_float), ("top_p", C.c_float), ("rep_penalty", C.c_float), ("rep_window", C.c_int32),
+                ("max_new_tokens", C.c_int32), ("n_stop", C.c_int32), ("stop_ids", C.c_int32 * 4), ("reserved", C.c_int32)]
+
+
+def _declare(lib):
+    if getattr(lib, "_lm_declared", False):
+        return
+    vp, i32 = C.c_void_p, C.c_int
+    lib.mia_lm_load.restype = vp
+    lib.mia_lm_load.argtypes = [vp, C.POINTER(_LmCfg), C.POINTER(_TensorView), i32, i32]
+    lib.mia_lm_free.restype = None
+    lib.mia_lm_free.argtypes = [vp]
+    lib.mia_lm_reset.restype = i32
+    lib.mia_lm_reset.argtypes = [vp]
+    lib.mia_lm_forward.restype = i32
+    lib.mia_lm_forward.argtypes = [vp, vp, i32, vp]
+    lib.mia_lm_generate.restype = i32
+    lib.mia_lm_generate.argtypes = [vp, vp, i32, C.POINTER(_Sampler), vp, vp, vp]
+    lib.mia_sample_top_p.restype = i32
+    lib.mia_sample_top_p.argtypes = [vp, vp, i32, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+    lib._lm_declared = True
+
+
+class CausalLM:
+    def __init__(self, ctx, h, cfg):
+        self.ctx, self.h, self.cfg = ctx, h, cfg
+
+    @staticmethod
+    def load(ctx: _lib.Context, cfg, weights: dict[str, np.ndarray], dtype: int = _lib.BF16) -> "CausalLM":
+        _declare(ctx.lib)
+        c = _LmCfg(cfg.vocab, cfg.hidden, cfg.inter, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.max_ctx, cfg.rms_eps,
+                   cfg.rope_theta, 1 if cfg.rope_llama3 else 0, cfg.rope_factor, cfg.rope_low, cfg.rope_high, cfg.rope_old_ctx,
+                   1 if cfg.qkv_bias else 0, 1 if cfg.tie_embeddings else 0)
+        views = (_TensorView * len(weights))()
+        keep = []
+        for i, (name, arr) in enumerate(weights.items()):
+            if arr.dtype == np.float16:
+                a, dt = np.ascontiguousarray(arr), _lib.F16
+            else:
+                a, dt = np.ascontiguousarray(arr, np.float32), _lib.F32
+            keep.append(a)
+            shp = (C.c_int64 * 4)(*(list(a.shape) + [0] * (4 - a.ndim)))
+            views[i] = _TensorView(name.encode(), dt, a.ndim, shp, a.ctypes.data)
+        h = ctx.lib.mia_lm_load(ctx.h, C.byref(c), views, len(weights), dtype)
+        if not h:
+            raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, ctx.lib.mia_last_error(ctx.h).decode())
+        return CausalLM(ctx, h, cfg)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.mia_lm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.ctx.check(self.ctx.lib.mia_lm_reset(self.h))
+
+    def forward(self, ids) -> np.ndarray:
+        """model(ids, cache)[0, -1]: fp32 logits after the last of `ids` (appended to the KV cache)."""
+        a = np.ascontiguousarray(ids, np.int32)
+        out = np.empty(self.cfg.vocab, np.float32)
+        self.ctx.check(self.ctx.lib.mia_lm_forward(self.h, a.ctypes.data, a.size, out.ctypes.data))
+        return out
+
+    def generate(self, prompt, uniforms, temperature=0.6, top_p=0.8, rep_penalty=1.3, rep_window=REPETITION_CONTEXT_SIZE,
+                 max_new_tokens=MAX_TOKEN_COUNT, stop_ids=(END_TOKEN,)) -> list[int]:
+        a = np.ascontiguousarray(prompt, np.int32)
+        u = np.ascontiguousarray(uniforms, np.float32)
+        if u.size < max_new_tokens:
+            raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, "need one uniform per possible draw")
+        sp = _Sampler(temperature, top_p, rep_penalty, rep_window, max_new_tokens, len(stop_ids), (C.c_int32 * 4)(*(list(stop_ids) + [0] * (4 - len(stop_ids)))), 0)
+        out = np.zeros(max_new_tokens, np.int32)
+        n = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.mia_lm_generate(self.h, a.ctypes.data, a.size, C.byref(sp), u.ctypes.data, out.ctypes.data, C.byref(n)))
+        return out[:n.value].tolist()
+
+
+def sample_next_token(ctx: _lib.Context, logits: np.ndarray, history, uniform: float, temperature=0.6, top_p=0.8, rep_penalty=1.3) -> int:
+    """sampleNextToken(logits:history:temperature:topP:repetitionPenalty:) with an explicit uniform for the categorical draw."""
+    _declare(ctx.lib)
+    lg = np.ascontiguousarray(logits, np.float32)
+    h = np.ascontiguousarray(history, np.int32)
+    out = C.c_int32(0)
+    ctx.check(ctx.lib.mia_sample_top_p(ctx.h, lg.ctypes.data, lg.size, h.ctypes.data if h.size else None, h.size, rep_penalty, temperature, top_p,
+                                       uniform, C.byref(out)))
+    return out.value
+
+
+def parse_output(tokens: list[int]) -> list[list[int]]:
+    """parseOutput (OrpheusTTS.swift:472-508): generated ids -> SNAC code lists [N, 2N, 4N] (host integer logic, as in the Swift)."""
+    last = max((i for i, t in enumerate(tokens) if t == AUDIO_CODE_DATA_START_MARKER), default=-1)
+    rel = tokens[last + 1:] if last >= 0 else tokens
+    f = [t for t in rel if t != END_TOKEN and t >= CODE_OFFSET]
+    f = [t - CODE_OFFSET for t in f[:(len(f) // 7) * 7]]
+    l1, l2, l3 = [], [], []
+    for i in range(len(f) // 7):
+        b = 7 * i
+        l1.append(f[b]); l2.append(f[b + 1] - 4096); l3.append(f[b + 2] - 2 * 4096); l3.append(f[b + 3] - 3 * 4096)
+        l2.append(f[b + 4] - 4 * 4096); l3.append(f[b + 5] - 5 * 4096); l3.append(f[b + 6] - 6 * 4096)
+    return [l1, l2, l3]

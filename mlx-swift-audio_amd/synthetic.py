@@ -268,3 +268,73 @@ def dac_weights(cfg: DACConfig, seed: int = 0) -> dict[str, np.ndarray]:
     alpha(f"{P}{1 + n}.alpha", cin)
     conv(f"{P}{2 + n}", 1, 7, cin)
     return w
+
+
+# ---- autoregressive LMs ------------------------------------------------------------------------------------------
+@dataclass
+class LMConfig:
+    vocab: int
+    hidden: int
+    inter: int
+    n_layers: int
+    n_heads: int
+    n_kv_heads: int
+    head_dim: int
+    max_ctx: int = 2048
+    rms_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_llama3: bool = True
+    rope_factor: float = 32.0
+    rope_low: float = 1.0
+    rope_high: float = 4.0
+    rope_old_ctx: int = 8192
+    qkv_bias: bool = False
+    tie_embeddings: bool = True
+
+
+LM_CONFIGS = {
+    # OrpheusConfig (TransformerBlock.swift:16-34) == Llama-3.2-3B with the Orpheus vocabulary
+    "orpheus-3b": LMConfig(156940, 3072, 8192, 28, 24, 8, 128, 2048),
+    # Qwen2Config defaults (Qwen2LM.swift:15-43): the CosyVoice2-0.5B backbone
+    "qwen2-0.5b": LMConfig(151936, 896, 4864, 24, 14, 2, 64, 2048, 1e-6, 1e6, False, 1.0, 1.0, 4.0, 8192, True, True),
+    "llama-micro": LMConfig(3000, 256, 512, 2, 4, 2, 64, 256),
+    "llama-micro128": LMConfig(3000, 256, 512, 2, 2, 1, 128, 256),
+    "qwen-micro": LMConfig(3000, 128, 384, 2, 2, 1, 64, 256, 1e-6, 1e6, False, 1.0, 1.0, 4.0, 8192, True, True),
+}
+
+
+def lm_weights(cfg: LMConfig, seed: int = 0, round_to: str | None = None, dtype=np.float32) -> dict[str, np.ndarray]:
+    """Random-init causal-LM checkpoint (HF key schema).  N(0, 1/fan_in) matrices, RMSNorm weights ~ 1, embeddings N(0,1)
+    scaled so the tied logits have a usable spread."""
+    w: dict[str, np.ndarray] = {}
+    D, dh = cfg.hidden, cfg.head_dim
+
+    def mat(name, rows, cols, std=None):
+        rng = np.random.Generator(np.random.PCG64(_key_seed(name, seed)))
+        a = rng.standard_normal((rows, cols), dtype=np.float32) * np.float32(std if std is not None else 1.0 / math.sqrt(cols))
+        w[name] = round_array(a, round_to).astype(dtype)
+
+    def vec(name, n, base, jitter):
+        rng = np.random.Generator(np.random.PCG64(_key_seed(name, seed)))
+        w[name] = round_array((base + jitter * rng.standard_normal(n)).astype(np.float32), None)
+
+    mat("model.embed_tokens.weight", cfg.vocab, D, 1.0 / math.sqrt(D) * 3.0)
+    if not cfg.tie_embeddings:
+        mat("lm_head.weight", cfg.vocab, D)
+    vec("model.norm.weight", D, 1.0, 0.1)
+    for l in range(cfg.n_layers):
+        p = f"model.layers.{l}"
+        vec(p + ".input_layernorm.weight", D, 1.0, 0.1)
+        vec(p + ".post_attention_layernorm.weight", D, 1.0, 0.1)
+        mat(p + ".self_attn.q_proj.weight", cfg.n_heads * dh, D)
+        mat(p + ".self_attn.k_proj.weight", cfg.n_kv_heads * dh, D)
+        mat(p + ".self_attn.v_proj.weight", cfg.n_kv_heads * dh, D)
+        mat(p + ".self_attn.o_proj.weight", D, cfg.n_heads * dh)
+        if cfg.qkv_bias:
+            vec(p + ".self_attn.q_proj.bias", cfg.n_heads * dh, 0.0, 0.1)
+            vec(p + ".self_attn.k_proj.bias", cfg.n_kv_heads * dh, 0.0, 0.1)
+            vec(p + ".self_attn.v_proj.bias", cfg.n_kv_heads * dh, 0.0, 0.1)
+        mat(p + ".mlp.gate_proj.weight", cfg.inter, D)
+        mat(p + ".mlp.up_proj.weight", cfg.inter, D)
+        mat(p + ".mlp.down_proj.weight", D, cfg.inter)
+    return w
