@@ -137,7 +137,14 @@ typedef struct {
   int32_t max_initial_timestamp_index; /* 50 (WhisperDecoding.swift:281) */
   int32_t max_new_tokens;        /* extra cap on generated tokens per clip (0 = none); benchmarking aid */
   float temperature;             /* 0 = greedy (argmax).  > 0: inverse-CDF sampling with caller-provided uniforms */
-  const float* uniforms;         /* [B][max_tokens] in [0,1) when temperature > 0 (explicit RNG), else NULL */
+  const float* uniforms;         /* [B][max_tokens] in [0,1) when any temperature > 0 (explicit RNG), else NULL */
+  /* optional per-clip overrides (NULL = use the scalar fields): prefixes of different length (prompt conditioning differs per
+   * clip: initial_tokens is then [B][n_initial] with n_initial_per_clip[b] valid entries per row), the fallback temperature
+   * of each clip (WhisperSTT.swift:195-250) and which clips take part in this call (inactive clips are left untouched). */
+  const int32_t* n_initial_per_clip;
+  const int32_t* sot_index_per_clip;
+  const float* clip_temperature;
+  const int32_t* clip_active;
 } mia_decode_opts;
 
 /* Replaces WhisperModel.load's tensor upload (STT/Whisper/WhisperModel.swift:184-206).  compute_dtype is MIA_BF16

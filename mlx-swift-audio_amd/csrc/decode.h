@@ -10,7 +10,7 @@ struct SkinnyArgs {
   const float* bias;
   void* out; int64_t ldo;                // OUT16 / OUTF32: [M][ldo];  PARTIAL: [S][M][N];  QKV: q [M][D]
   uint16_t* cache_k; uint16_t* cache_v;  // QKV: [B][H][n_ctx][64] of this layer
-  const DecState* st;
+  const int32_t* pos;                    // QKV: per-row (clip) cache position
   int M, N, K, S, act, D, H, n_ctx;
 };
 

@@ -59,10 +59,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void dec_embed_ln(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ emb,
                                                     const float* __restrict__ pos_emb, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float* __restrict__ x,
-                                                    uint16_t* __restrict__ h, const DecState* __restrict__ st, int D, int n_ctx) {
+                                                    uint16_t* __restrict__ h, const int32_t* __restrict__ pos_arr, int D, int n_ctx) {
   __shared__ float sh[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int pos = st->pos;
+  const int pos = pos_arr[b];
   const int tok = tokens[b * n_ctx + pos];
   const uint16_t* e = emb + (int64_t)tok * D;
   const float* p = pos_emb + (int64_t)pos * D;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64) void dec_skinny_gemm(SkinnyArgs a) {
           else {
             const int hd = (nn - a.D) % a.D, h = hd >> 6, d = hd & 63;
             uint16_t* cache = nn < 2 * a.D ? a.cache_k : a.cache_v;
-            cache[(((int64_t)m * a.H + h) * a.n_ctx + a.st->pos) * 64 + d] = T::from_f32(v);
+            cache[(((int64_t)m * a.H + h) * a.n_ctx + a.pos[m]) * 64 + d] = T::from_f32(v);
           }
         }
       }
@@ -241,14 +241,14 @@ __global__ __launch_bounds__(64) void dec_skinny_gemm(SkinnyArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Single-query attention against a head-major K/V cache: one workgroup per (head, clip).
 // 8 lanes share a key (16 B each, fully coalesced 1 KB per wave instruction); fp32 softmax.
-// n_keys = st->pos + 1 (self attention) or the constant T (cross attention).
+// n_keys = pos[clip] + 1 (self attention) or the constant T (cross attention).
 // ------------------------------------------------------------------------------------------------
 constexpr int DEC_MAX_KEYS = 1536;
 
 template <typename T>
 __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
                                                      const uint16_t* __restrict__ vc, uint16_t* __restrict__ out,
-                                                     const DecState* __restrict__ st, int fixed_keys, int cap_keys, int H,
+                                                     const int32_t* __restrict__ pos_arr, int fixed_keys, int cap_keys, int H,
                                                      float scale) {
   __shared__ float sc[DEC_MAX_KEYS];
   __shared__ float red[4][64];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, b = blockIdx.y;
   const int D = H * 64;
-  const int nk = fixed_keys > 0 ? fixed_keys : st->pos + 1;
+  const int nk = fixed_keys > 0 ? fixed_keys : pos_arr[b] + 1;
   const int c = lane & 7, g = lane >> 3;
   const uint16_t* kb = kc + ((int64_t)b * H + h) * cap_keys * 64;
   const uint16_t* vb = vc + ((int64_t)b * H + h) * cap_keys * 64;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // Decode head: logit rules + argmax + log-prob bookkeeping (WhisperDecoding.swift:158-169,186-358), one workgroup
-// per clip, all reductions in fp32.  Also advances nothing: dec_advance bumps the position afterwards.
+// per clip, all reductions in fp32; each block advances its own clip's position.
 // ------------------------------------------------------------------------------------------------
 struct HeadBufs {
   const float* logits;          // [B][V]
@@ -350,7 +350,8 @@ struct HeadBufs {
   int32_t* n_logprob;           // [B]
   float* no_speech;             // [B]
   const uint32_t* suppress;     // [2][nw]
-  DecState* st;
+  const float* uniforms;        // [B][n_ctx] explicit RNG for temperature > 0 (one value per generated token)
+  DecClip clip;
 };
 
 constexpr int HEAD_NPT = 52;   // logits per thread held in registers: V <= 1024 * 52
@@ -367,37 +368,35 @@ __device__ __forceinline__ ArgMax wave_amax(ArgMax a) {
   return a;
 }
 
-// Two passes over the clip's logits (L2 resident): pass 1 = every max / argmax, pass 2 = every exp-sum.
-// The timestamp heuristic (:299-322) decides between two precomputed candidates: A = rules only, B = rules + "text
-// suppressed".  log-sum-exps use the max-shifted form; ts_lse = (max_ts - lse) + log(sum_ts exp(x - max_ts)).
-// Every block reads st->pos first; the block that draws the last ticket (all others have read pos long before they
-// take theirs) advances the position for the next step, so no separate "advance" launch is needed.
-__device__ __forceinline__ void head_ticket(DecState* st, int B) {
-  __syncthreads();                                    // every wave of this block has read st->pos by now
-  if (threadIdx.x == 0) {
-    const int t = atomicAdd(&st->active, 1);
-    if (t == B - 1) { st->active = 0; st->pos += 1; }
-  }
-}
-
+// One workgroup per clip.  The clip's logits are read once into registers; pass 1 = every max / argmax, pass 2 = every
+// exp-sum.  The timestamp heuristic (:299-322) decides between two precomputed candidates: A = rules only, B = rules +
+// "text suppressed".  ts_lse = (max_ts - lse) + log(sum_ts exp(x - max_ts)).  temperature > 0: inverse-CDF sampling of
+// softmax(filtered / T) with the caller's uniform (sampleFromDistribution, :395-410: first index whose cumsum >= r).
+// Each block advances its own clip's position; a finished clip stops advancing.
 __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
   __shared__ float shf[16][4];
   __shared__ float sha[16][2];
   __shared__ int shai[16][2];
+  __shared__ float seg[HEAD_NPT * 16];
+  __shared__ int s_pick[2];
+  __shared__ float s_val[2];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = p.V;
   const float* lg = hb.logits + (int64_t)b * V;
-  const int pos = hb.st->pos;
+  const int pos = hb.clip.pos[b];
+  const int n_initial = hb.clip.n_init[b], sot_index = hb.clip.sot_idx[b];
+  const float temperature = hb.clip.temp[b];
   const int cur_len = pos + 1;
   int32_t* toks = hb.tokens + (int64_t)b * p.n_ctx;
-  const bool generating = cur_len >= p.n_initial;
-  if (!generating && pos != p.sot_index) { head_ticket(hb.st, p.B); return; }   // forced token, no probe: nothing to do
-  if (generating && hb.finished[b]) {
-    if (tid == 0 && cur_len < p.n_ctx) toks[cur_len] = p.eot;
-    if (pos != p.sot_index) { head_ticket(hb.st, p.B); return; }
+  const bool generating = cur_len >= n_initial;
+  if (generating && hb.finished[b]) return;           // done: the clip idles at its last position
+  if (!generating && pos != sot_index) {              // forced token and no probe wanted: just advance
+    __syncthreads();
+    if (tid == 0) hb.clip.pos[b] = pos + 1;
+    return;
   }
-  const bool decide = generating && !hb.finished[b];
-  const int num_gen = cur_len - p.n_initial;          // == loop iteration of the reference
+  const bool decide = generating;
+  const int num_gen = cur_len - n_initial;            // == loop iteration of the reference
   const int tsb = p.timestamp_begin;
 
   // ---- rule state (WhisperDecoding.swift:221-292)
@@ -480,43 +479,92 @@ __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
   s_all = wave_sum(s_all); s_ts = wave_sum(s_ts); fA = wave_sum(fA); fB = wave_sum(fB);
   if (lane == 0) { shf[wave][0] = s_all; shf[wave][1] = s_ts; shf[wave][2] = fA; shf[wave][3] = fB; }
   __syncthreads();
-  head_ticket(hb.st, p.B);
-  if (tid != 0) return;
   s_all = s_ts = fA = fB = 0.f;
   for (int w2 = 0; w2 < 16; ++w2) { s_all += shf[w2][0]; s_ts += shf[w2][1]; fA += shf[w2][2]; fB += shf[w2][3]; }
   const float lse = mx_all + __logf(s_all);
-  if (pos == p.sot_index) hb.no_speech[b] = __expf(lg[p.no_speech] - lse);   // softmax(logits[sot])[no_speech] (:158-169)
-  if (!decide) return;
-  ArgMax best = bA; float fsum = fA;
+  if (pos == sot_index && tid == 0) hb.no_speech[b] = __expf(lg[p.no_speech] - lse);   // softmax(logits[sot])[no_speech] (:158-169)
+  if (!decide) {
+    if (tid == 0) hb.clip.pos[b] = pos + 1;
+    return;
+  }
+  bool useB = false;
   if (heuristic) {
     const float ts_lse = (mx_ts - lse) + __logf(s_ts);
     const float max_text = mx_text - lse;
-    if (ts_lse > max_text) { best = bB; fsum = fB; }   // force a timestamp: text tokens suppressed too
+    useB = ts_lse > max_text;                         // force a timestamp: text tokens suppressed too
   }
+  const ArgMax best = useB ? bB : bA;
+  const float fsum = useB ? fB : fA;
   // Everything masked: reachable in the reference when the raw-logit timestamp heuristic fires right after a
   // timestamp pair rule; MLX argMax of an all -inf vector is index 0 and log(softmax) is NaN.  Mirror that.
   const bool all_masked = best.i == 0x7fffffff;
-  const int next = all_masked ? 0 : best.i;
+  int next = all_masked ? 0 : best.i;
+
+  if (temperature > 0.0f && !all_masked) {
+    // ---- sampling: p_i ~ exp((x_i - max) / T) over the kept set, first index whose cumulative sum >= r * total
+    const float inv_t = 1.0f / temperature;
+    auto weight = [&](int u) -> float {
+      const int i = tid + 1024 * u;
+      const bool kept = ((okA >> u) & 1ull) && (!useB || i >= tsb);
+      return kept ? __expf((x[u] - best.v) * inv_t) : 0.f;
+    };
+#pragma unroll
+    for (int u = 0; u < HEAD_NPT; ++u) {
+      const float ssum = wave_sum(weight(u));         // segment (u, wave) covers indices [1024u + 64*wave, +64): index-ordered
+      if (lane == 0) seg[u * 16 + wave] = ssum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float total = 0.f;
+      for (int k = 0; k < HEAD_NPT * 16; ++k) total += seg[k];
+      const float r = hb.uniforms[(int64_t)b * p.n_ctx + num_gen];
+      const float goal = r * total;
+      float cum = 0.f; int sel = -1;
+      for (int k = 0; k < HEAD_NPT * 16; ++k) {
+        if (seg[k] > 0.f && cum + seg[k] >= goal) { sel = k; break; }
+        cum += seg[k];
+      }
+      if (sel < 0) { for (int k = HEAD_NPT * 16 - 1; k >= 0; --k) if (seg[k] > 0.f) { sel = k; break; } cum -= 0.f; }
+      s_pick[0] = sel; s_val[0] = cum; s_val[1] = goal;
+    }
+    __syncthreads();
+    const int sel = s_pick[0];
+    if (sel >= 0 && wave == (sel & 15)) {
+      const int u_sel = sel >> 4;
+      float mine = 0.f;
+#pragma unroll
+      for (int u = 0; u < HEAD_NPT; ++u) if (u == u_sel) mine = weight(u);
+      float incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      const unsigned long long hit = __ballot(mine > 0.f && s_val[0] + incl >= s_val[1]);
+      const unsigned long long any = __ballot(mine > 0.f);
+      int ln = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)any);   // rounding corner: last kept lane of the segment
+      if (lane == 0) s_pick[1] = 1024 * u_sel + 64 * wave + ln;
+    }
+    __syncthreads();
+    if (sel >= 0) next = s_pick[1];
+  }
+  if (tid != 0) return;
   if (next != p.eot) {                                // EOT excluded from avg_logprob (:345-350)
-    hb.sum_logprob[b] += all_masked ? __int_as_float(0x7fc00000) : -__logf(fsum);
+    hb.sum_logprob[b] += all_masked ? __int_as_float(0x7fc00000) : (lg[next] - best.v) - __logf(fsum);
     hb.n_logprob[b] += 1;
   }
   toks[cur_len] = next;
   hb.n_gen[b] = num_gen + 1;
   if (next > tsb) hb.last_ts[b] = next;               // strict '>' (:254-256)
-  int cap = p.max_tokens - p.n_initial;
+  int cap = p.max_tokens - n_initial;
   if (p.max_new_tokens > 0 && p.max_new_tokens < cap) cap = p.max_new_tokens;
   if (next == p.eot || num_gen + 1 >= cap) hb.finished[b] = 1;
+  else hb.clip.pos[b] = pos + 1;
 }
-
-__global__ void dec_advance(DecState* st) { st->pos += 1; }
 
 // compact outputs: generated tokens with EOT (and anything after) stripped; avg_logprob
 __global__ void dec_finalize(const int32_t* __restrict__ tokens, const int32_t* __restrict__ n_gen,
                              const float* __restrict__ sum_lp, const int32_t* __restrict__ n_lp, int32_t* __restrict__ out_tokens,
-                             int32_t* __restrict__ out_n, float* __restrict__ out_avg, DecodeParams p) {
+                             int32_t* __restrict__ out_n, float* __restrict__ out_avg, const int32_t* __restrict__ n_init, DecodeParams p) {
   const int b = blockIdx.x;
-  const int32_t* t = tokens + (int64_t)b * p.n_ctx + p.n_initial;
+  const int32_t* t = tokens + (int64_t)b * p.n_ctx + n_init[b];
   __shared__ int n_keep;
   if (threadIdx.x == 0) {
     int n = n_gen[b];
@@ -535,9 +583,9 @@ __global__ void dec_finalize(const int32_t* __restrict__ tokens, const int32_t* 
 int dec_launch_embed_ln(mia_whisper* w, const LNW& ln, hipStream_t s) {
   const int D = w->dims.n_text_state;
   if (w->dtype == MIA_F16)
-    hipLaunchKernelGGL(dec_embed_ln<F16>, dim3(w->cur_B), dim3(256), 0, s, w->tokens, (const uint16_t*)w->tok_emb, w->dec_pos, ln.g, ln.b, w->dx, (uint16_t*)w->dh, w->state, D, w->dims.n_text_ctx);
+    hipLaunchKernelGGL(dec_embed_ln<F16>, dim3(w->cur_B), dim3(256), 0, s, w->tokens, (const uint16_t*)w->tok_emb, w->dec_pos, ln.g, ln.b, w->dx, (uint16_t*)w->dh, w->clip.pos, D, w->dims.n_text_ctx);
   else
-    hipLaunchKernelGGL(dec_embed_ln<BF16>, dim3(w->cur_B), dim3(256), 0, s, w->tokens, (const uint16_t*)w->tok_emb, w->dec_pos, ln.g, ln.b, w->dx, (uint16_t*)w->dh, w->state, D, w->dims.n_text_ctx);
+    hipLaunchKernelGGL(dec_embed_ln<BF16>, dim3(w->cur_B), dim3(256), 0, s, w->tokens, (const uint16_t*)w->tok_emb, w->dec_pos, ln.g, ln.b, w->dx, (uint16_t*)w->dh, w->clip.pos, D, w->dims.n_text_ctx);
   return 0;
 }
 
@@ -581,20 +629,20 @@ int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const vo
   if (cap_keys > DEC_MAX_KEYS) return -1;
   dim3 grid(w->dims.n_text_head, w->cur_B), block(256);
   if (w->dtype == MIA_F16)
-    hipLaunchKernelGGL(dec_attention<F16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->state, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f);
+    hipLaunchKernelGGL(dec_attention<F16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->clip.pos, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f);
   else
-    hipLaunchKernelGGL(dec_attention<BF16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->state, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f);
+    hipLaunchKernelGGL(dec_attention<BF16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->clip.pos, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f);
   return 0;
 }
 
 int dec_launch_head(mia_whisper* w, int32_t* last_ts, const DecodeParams& p, hipStream_t s) {
   if (p.V > 1024 * HEAD_NPT) return -1;
-  HeadBufs hb{w->logits, w->tokens, w->n_gen, w->finished, last_ts, w->sum_logprob, w->n_logprob, w->no_speech, w->suppress_bits, w->state};
+  HeadBufs hb{w->logits, w->tokens, w->n_gen, w->finished, last_ts, w->sum_logprob, w->n_logprob, w->no_speech, w->suppress_bits, w->uniforms, w->clip};
   hipLaunchKernelGGL(dec_head, dim3(w->cur_B), dim3(1024), 0, s, hb, p);
   return 0;
 }
 
 int dec_launch_finalize(mia_whisper* w, int32_t* out_n, const DecodeParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(dec_finalize, dim3(w->cur_B), dim3(256), 0, s, w->tokens, w->n_gen, w->sum_logprob, w->n_logprob, w->out_tokens, out_n, w->out_avg, p);
+  hipLaunchKernelGGL(dec_finalize, dim3(w->cur_B), dim3(256), 0, s, w->tokens, w->n_gen, w->sum_logprob, w->n_logprob, w->out_tokens, out_n, w->out_avg, w->clip.n_init, p);
   return 0;
 }

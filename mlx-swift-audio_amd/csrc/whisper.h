@@ -41,19 +41,19 @@ struct DecBlockW {
   LinearW mlp1, mlp2;
 };
 
-// device-side decode state shared by every kernel of a step (so the step can be replayed as one hipGraph)
-struct DecState {
-  int pos;          // tokens already in the self-KV cache == position of the token being consumed
-  int n_initial;    // length of the initial (forced) sequence
-  int active;       // clips still decoding (updated by the head kernel)
+// Per-clip decode state, device arrays [B] read by every kernel of a step (so ONE captured hipGraph replays for every step
+// and every call).  Clips of a batch may sit at different positions: forced prefixes (prompt conditioning) differ in length.
+struct DecClip {
+  int32_t* pos;       // tokens already in the self-KV cache == position of the token being consumed
+  int32_t* n_init;    // length of the forced prefix ([sot_prev]+prompt+sot sequence)
+  int32_t* sot_idx;   // position of <|startoftranscript|> (no-speech probe)
+  float* temp;        // sampling temperature (0 = greedy argmax)
 };
 
-struct DecodeParams {  // immutable per decode call (kernel argument, by value)
+struct DecodeParams {  // immutable per graph (kernel argument, by value)
   int B, V, D, H, L, n_ctx;     // n_ctx = n_text_ctx (448)
-  int n_initial, sot_index;
   int eot, no_speech, no_timestamps, timestamp_begin;
   int timestamps, max_tokens, max_initial_ts, max_new_tokens;
-  float temperature;
 };
 
 struct mia_whisper {
@@ -108,7 +108,7 @@ struct mia_whisper {
   float* no_speech = nullptr;         // fp32 [B]
   uint32_t* suppress_bits = nullptr;  // [2][ceil(V/32)]  base mask, base+first-step mask
   float* uniforms = nullptr;          // fp32 [B][n_ctx]
-  DecState* state = nullptr;
+  DecClip clip{};
   int32_t* out_tokens = nullptr;      // int32 [B][n_ctx] compacted outputs
   float* out_avg = nullptr;           // fp32 [B]
   hipGraphExec_t step_graph = nullptr;

@@ -4,6 +4,7 @@
 //
 // Prefill note: the reference feeds the n_initial forced tokens in one causal pass; here they are fed one position
 // per step through the same graph (mathematically identical: causal attention only sees earlier positions).
+#include <algorithm>
 #include <cstdlib>
 
 #include "decode.h"
@@ -22,7 +23,7 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p) {
   const uint16_t* dh = (const uint16_t*)w->dh;
   auto skinny = [&](const uint16_t* A, int64_t lda, const LinearW& lw, bool use_bias, void* out, int64_t ldo, int S, int act, int mode,
                     uint16_t* ck = nullptr, uint16_t* cv = nullptr) {
-    SkinnyArgs a{A, lda, (const uint16_t*)lw.w, use_bias ? lw.b : nullptr, out, ldo, ck, cv, w->state, B, lw.N, lw.K, S, act, D, H, C};
+    SkinnyArgs a{A, lda, (const uint16_t*)lw.w, use_bias ? lw.b : nullptr, out, ldo, ck, cv, w->clip.pos, B, lw.N, lw.K, S, act, D, H, C};
     return dec_launch_skinny(w, a, mode, s);
   };
   const int S_d = pick_split(D, 8), S_4d = pick_split(4 * D, 16);
@@ -65,14 +66,12 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
   MIA_CHECK_ARG(ctx, w->cur_B > 0, "decode: no audio features (call mia_whisper_encode first)");
   MIA_CHECK_ARG(ctx, o && o->initial_tokens && o->n_initial > 0, "decode: initial_tokens required");
   MIA_CHECK_ARG(ctx, o->max_tokens > 0 && o->max_tokens <= d.n_text_ctx, "decode: max_tokens must be in 1..n_text_ctx");
-  // The Swift computes maxGenerate = maxTokens - initial and traps when that goes negative: clamp + report.
+  // The Swift computes maxGenerate = maxTokens - initial and traps when that goes negative: reject instead.
   MIA_CHECK_ARG(ctx, o->n_initial < o->max_tokens, "decode: initial sequence (%d) leaves no room under max_tokens (%d)", o->n_initial, o->max_tokens);
-  MIA_CHECK_ARG(ctx, o->sot_index >= 0 && o->sot_index < o->n_initial, "decode: sot_index out of range");
   MIA_CHECK_ARG(ctx, o->eot >= 0 && o->eot < d.n_vocab && o->no_speech >= 0 && o->no_speech < d.n_vocab &&
                          o->timestamp_begin > 0 && o->timestamp_begin <= d.n_vocab && o->no_timestamps >= 0 && o->no_timestamps < d.n_vocab,
                 "decode: special token ids out of range");
   MIA_CHECK_ARG(ctx, o->n_suppress >= 0 && o->n_blank >= 0 && (o->n_suppress == 0 || o->suppress_ids) && (o->n_blank == 0 || o->blank_ids), "decode: bad suppress tables");
-  if (o->temperature != 0.0f) return mia_fail(ctx, MIA_ERR_UNSUPPORTED, "decode: temperature > 0 sampling is not implemented yet (greedy only)");
   MIA_CHECK_ARG(ctx, mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE, "decode: bad mem");
   MIA_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -80,21 +79,36 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
 
   DecodeParams p{};
   p.B = B; p.V = V; p.D = d.n_text_state; p.H = d.n_text_head; p.L = d.n_text_layer; p.n_ctx = C;
-  p.n_initial = o->n_initial; p.sot_index = o->sot_index;
   p.eot = o->eot; p.no_speech = o->no_speech; p.no_timestamps = o->no_timestamps; p.timestamp_begin = o->timestamp_begin;
   p.timestamps = o->timestamps ? 1 : 0; p.max_tokens = o->max_tokens;
   p.max_initial_ts = o->max_initial_timestamp_index; p.max_new_tokens = o->max_new_tokens;
-  p.temperature = o->temperature;
 
-  // ---- upload per-call tables: initial tokens, suppress bit masks (host -> device, small)
+  // ---- per-clip forced prefixes, probe positions, temperatures, activity (host -> device, small)
+  std::vector<int32_t> n_init(B), sot_idx(B), fin(B, 0);
+  std::vector<float> temp(B);
+  int total_steps = 0; bool any_sampling = false;
   {
     std::vector<int32_t> init((size_t)B * C, 0);
-    for (int b = 0; b < B; ++b)
-      for (int i = 0; i < o->n_initial; ++i) {
+    for (int b = 0; b < B; ++b) {
+      const int ni = (o->per_clip_initial && o->n_initial_per_clip) ? o->n_initial_per_clip[b] : o->n_initial;
+      MIA_CHECK_ARG(ctx, ni > 0 && ni <= o->n_initial && ni < o->max_tokens, "decode: clip %d: bad initial length %d", b, ni);
+      n_init[b] = ni;
+      sot_idx[b] = o->sot_index_per_clip ? o->sot_index_per_clip[b] : o->sot_index;
+      MIA_CHECK_ARG(ctx, sot_idx[b] >= 0 && sot_idx[b] < ni, "decode: clip %d: sot_index out of range", b);
+      temp[b] = o->clip_temperature ? o->clip_temperature[b] : o->temperature;
+      MIA_CHECK_ARG(ctx, temp[b] >= 0.0f, "decode: negative temperature");
+      if (temp[b] > 0.0f) any_sampling = true;
+      if (o->clip_active && !o->clip_active[b]) fin[b] = 1;
+      for (int i = 0; i < ni; ++i) {
         const int32_t t = o->per_clip_initial ? o->initial_tokens[(size_t)b * o->n_initial + i] : o->initial_tokens[i];
         if (t < 0 || t >= V) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "decode: initial token %d out of vocabulary", t);
         init[(size_t)b * C + i] = t;
       }
+      int cap = p.max_tokens - ni;
+      if (p.max_new_tokens > 0 && p.max_new_tokens < cap) cap = p.max_new_tokens;
+      if (!fin[b]) total_steps = std::max(total_steps, ni + cap - 1);
+    }
+    MIA_CHECK_ARG(ctx, !any_sampling || o->uniforms, "decode: temperature > 0 needs caller-provided uniforms [B][max_tokens]");
     const int nw = (V + 31) / 32;
     std::vector<uint32_t> bits((size_t)2 * nw, 0u);
     auto setbit = [&](int set, int id) { if (id >= 0 && id < V) bits[(size_t)set * nw + (id >> 5)] |= 1u << (id & 31); };
@@ -103,17 +117,25 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
     setbit(1, o->eot);
     MIA_HIP(ctx, hipMemcpyAsync(w->tokens, init.data(), init.size() * 4, hipMemcpyHostToDevice, s));
     MIA_HIP(ctx, hipMemcpyAsync(w->suppress_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, s));
+    MIA_HIP(ctx, hipMemcpyAsync(w->clip.n_init, n_init.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    MIA_HIP(ctx, hipMemcpyAsync(w->clip.sot_idx, sot_idx.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    MIA_HIP(ctx, hipMemcpyAsync(w->clip.temp, temp.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    MIA_HIP(ctx, hipMemcpyAsync(w->finished, fin.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    if (any_sampling) {
+      // uniforms arrive as [B][max_tokens]; the kernel indexes [B][n_ctx]
+      for (int b = 0; b < B; ++b)
+        MIA_HIP(ctx, hipMemcpyAsync(w->uniforms + (size_t)b * C, o->uniforms + (size_t)b * o->max_tokens, (size_t)o->max_tokens * 4, hipMemcpyHostToDevice, s));
+    }
     MIA_HIP(ctx, hipStreamSynchronize(s));   // host vectors go out of scope
   }
   MIA_HIP(ctx, hipMemsetAsync(w->n_gen, 0, (size_t)B * 4, s));
-  MIA_HIP(ctx, hipMemsetAsync(w->finished, 0, (size_t)B * 4, s));
   MIA_HIP(ctx, hipMemsetAsync(w->last_ts, 0, (size_t)B * 4, s));
   MIA_HIP(ctx, hipMemsetAsync(w->sum_logprob, 0, (size_t)B * 4, s));
   MIA_HIP(ctx, hipMemsetAsync(w->n_logprob, 0, (size_t)B * 4, s));
   MIA_HIP(ctx, hipMemsetAsync(w->no_speech, 0, (size_t)B * 4, s));
-  MIA_HIP(ctx, hipMemsetAsync(w->state, 0, sizeof(DecState), s));
+  MIA_HIP(ctx, hipMemsetAsync(w->clip.pos, 0, (size_t)B * 4, s));
 
-  // ---- one hipGraph per (batch, params): every kernel reads the position from DecState
+  // ---- one hipGraph per (batch, rule set): every kernel reads per-clip positions from device memory
   static const bool no_graph = getenv("MIA_NO_GRAPH") != nullptr;
   if (!no_graph && (!w->graph_valid || memcmp(&w->graph_params, &p, sizeof(p)) != 0)) {
     if (w->step_graph) { (void)hipGraphExecDestroy(w->step_graph); w->step_graph = nullptr; }
@@ -132,18 +154,15 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
     w->graph_valid = true;
   }
 
-  int cap = p.max_tokens - p.n_initial;
-  if (p.max_new_tokens > 0 && p.max_new_tokens < cap) cap = p.max_new_tokens;
-  const int total_steps = p.n_initial + cap - 1;
-  std::vector<int32_t> fin(B);
   int prof_rec = mia_prof_begin(ctx, MIA_PROF_DECODE, 0.0);
   int steps_run = 0;
+  const int min_init = *std::min_element(n_init.begin(), n_init.end());
   for (int step = 0; step < total_steps; ++step) {
     ++steps_run;
     if (no_graph) { if (enqueue_step(w, p) != 0) return mia_fail(ctx, MIA_ERR_DEVICE, "decode: step launch failed"); }
     else MIA_HIP(ctx, hipGraphLaunch(w->step_graph, s));
     // early exit: poll the finished flags every 16 steps once generation has started
-    if (step >= p.n_initial && (step & 15) == 15 && step + 1 < total_steps) {
+    if (step >= min_init && (step & 15) == 15 && step + 1 < total_steps) {
       MIA_HIP(ctx, hipMemcpyAsync(fin.data(), w->finished, (size_t)B * 4, hipMemcpyDeviceToHost, s));
       MIA_HIP(ctx, hipStreamSynchronize(s));
       bool all = true;

@@ -86,7 +86,10 @@ int whisper_reserve(mia_whisper* w, int B) {
   A(w->out_tokens, (size_t)B * C * 4, true);
   A(w->out_avg, (size_t)B * 4, true);
   if (!w->suppress_bits) { A(w->suppress_bits, 2 * ((V + 31) / 32) * 4, true); }
-  if (!w->state) { A(w->state, sizeof(DecState), true); }
+  A(w->clip.pos, (size_t)B * 4, true);
+  A(w->clip.n_init, (size_t)B * 4, true);
+  A(w->clip.sot_idx, (size_t)B * 4, true);
+  A(w->clip.temp, (size_t)B * 4, true);
 #undef A
   w->cap_B = B;
   w->graph_valid = false;

@@ -129,3 +129,25 @@ def parse_output(tokens: list[int]) -> list[list[int]]:
         l1.append(f[b]); l2.append(f[b + 1] - 4096); l3.append(f[b + 2] - 2 * 4096); l3.append(f[b + 3] - 3 * 4096)
         l2.append(f[b + 4] - 4 * 4096); l3.append(f[b + 5] - 5 * 4096); l3.append(f[b + 6] - 6 * 4096)
     return [l1, l2, l3]
+
+
+class OrpheusTTS:
+    """generateChunk (TTS/Orpheus/TTSEngine/OrpheusTTS.swift:224-373) from token ids onward: LM sampling loop ->
+    parseOutput -> SNAC decode.  Text tokenisation / voice prefix / sentence splitting stay with the caller (CPU text code)."""
+
+    def __init__(self, lm: CausalLM, snac):
+        self.lm, self.snac = lm, snac
+
+    def generate_chunk(self, input_ids, uniforms, noise=None, temperature=0.6, top_p=0.8, max_new_tokens=MAX_TOKEN_COUNT):
+        gen = self.lm.generate(input_ids, uniforms, temperature=temperature, top_p=top_p, rep_penalty=1.3,
+                               rep_window=REPETITION_CONTEXT_SIZE, max_new_tokens=max_new_tokens, stop_ids=(END_TOKEN,))
+        codes = parse_output(list(input_ids) + gen)
+        if not codes[0]:
+            return gen, np.zeros(0, np.float32)
+        n = len(codes[0])
+        lim = self.snac.cfg.codebook_size
+        codes = [[min(max(c, 0), lim - 1) for c in lv] for lv in codes]     # random-init LMs emit out-of-layer ids; real ones do not
+        nz = noise
+        if noise is not None:
+            nz = np.ascontiguousarray(noise[:self.snac.noise_len(4 * n)], np.float32)
+        return gen, self.snac.decode(codes, nz)

@@ -35,7 +35,9 @@ class _DecodeOpts(C.Structure):
                 ("blank_ids", C.c_void_p), ("n_blank", C.c_int32),
                 ("eot", C.c_int32), ("no_speech", C.c_int32), ("no_timestamps", C.c_int32), ("timestamp_begin", C.c_int32),
                 ("timestamps", C.c_int32), ("max_tokens", C.c_int32), ("max_initial_timestamp_index", C.c_int32),
-                ("max_new_tokens", C.c_int32), ("temperature", C.c_float), ("uniforms", C.c_void_p)]
+                ("max_new_tokens", C.c_int32), ("temperature", C.c_float), ("uniforms", C.c_void_p),
+                ("n_initial_per_clip", C.c_void_p), ("sot_index_per_clip", C.c_void_p), ("clip_temperature", C.c_void_p),
+                ("clip_active", C.c_void_p)]
 
 
 def _declare(lib):
@@ -209,13 +211,46 @@ class WhisperModel:
         co = _DecodeOpts(init.ctypes.data, int(init.shape[-1]), per_clip, sot_index,
                          sup.ctypes.data if sup.size else None, int(sup.size), blank.ctypes.data if blank.size else None, int(blank.size),
                          st.eot, st.no_speech, st.no_timestamps, st.timestamp_begin, 1 if o.timestamps else 0, o.max_tokens,
-                         o.max_initial_timestamp_index, o.max_new_tokens, float(o.temperature), None)
+                         o.max_initial_timestamp_index, o.max_new_tokens, float(o.temperature), None, None, None, None, None)
         return co, keep
 
     def decode_greedy(self, o: DecodingOptions, initial: np.ndarray | None = None) -> list[DecodingResult]:
         """Greedy-decode the B clips of the last encode()."""
         co, keep = self._opts(o, initial)
         B = self.B
+        tokens = np.zeros((B, o.max_tokens), np.int32)
+        n = np.zeros(B, np.int32)
+        avg = np.zeros(B, np.float32)
+        nsp = np.zeros(B, np.float32)
+        self.ctx.check(self.ctx.lib.mia_whisper_decode_greedy(self.h, C.byref(co), tokens.ctypes.data, n.ctypes.data, avg.ctypes.data,
+                                                              nsp.ctypes.data, _lib.MEM_HOST))
+        return [DecodingResult(tokens[b, :n[b]].tolist(), float(avg[b]), float(nsp[b])) for b in range(B)]
+
+    def decode_ragged(self, o: DecodingOptions, initials: list[list[int]], sot_index: list[int], temperatures: list[float],
+                      uniforms: np.ndarray | None = None, active: list[bool] | None = None) -> list[DecodingResult]:
+        """Decode the B clips of the last encode() with per-clip forced prefixes / temperatures (the fallback + prompt
+        conditioning cases of WhisperSTT.transcribe).  uniforms [B, max_tokens] feed the T>0 draws."""
+        st = self.special
+        B = self.B
+        assert len(initials) == B and len(sot_index) == B and len(temperatures) == B
+        n_max = max(len(t) for t in initials)
+        init = np.zeros((B, n_max), np.int32)
+        for b, t in enumerate(initials):
+            init[b, :len(t)] = t
+        n_init = np.asarray([len(t) for t in initials], np.int32)
+        sot = np.asarray(sot_index, np.int32)
+        temps = np.asarray(temperatures, np.float32)
+        act = None if active is None else np.asarray([1 if a else 0 for a in active], np.int32)
+        uni = None if uniforms is None else np.ascontiguousarray(uniforms, np.float32)
+        if uni is not None and uni.shape != (B, o.max_tokens):
+            raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, f"uniforms must be [{B},{o.max_tokens}]")
+        sup = np.asarray(o.suppress_ids, np.int32)
+        blank = np.asarray(o.blank_ids, np.int32)
+        co = _DecodeOpts(init.ctypes.data, n_max, 1, int(sot[0]), sup.ctypes.data if sup.size else None, int(sup.size),
+                         blank.ctypes.data if blank.size else None, int(blank.size), st.eot, st.no_speech, st.no_timestamps, st.timestamp_begin,
+                         1 if o.timestamps else 0, o.max_tokens, o.max_initial_timestamp_index, o.max_new_tokens, 0.0,
+                         None if uni is None else uni.ctypes.data, n_init.ctypes.data, sot.ctypes.data, temps.ctypes.data,
+                         None if act is None else act.ctypes.data)
         tokens = np.zeros((B, o.max_tokens), np.int32)
         n = np.zeros(B, np.int32)
         avg = np.zeros(B, np.float32)

@@ -241,9 +241,17 @@ def initial_tokens(st: SpecialTokens, o: DecodingOptions) -> tuple[list[int], in
     return toks, sot_index
 
 
-def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: DecodingOptions) -> DecodingResult:
-    """GreedyDecoder.decode (WhisperDecoding.swift:96-389) for ONE clip (xa [1, n_audio_ctx, D]), temperature 0."""
-    assert o.temperature == 0.0, "the reference's T>0 path uses an unseeded system RNG; parity is defined at T=0 only"
+def sample_from_distribution(probs: np.ndarray, r: float) -> int:
+    """sampleFromDistribution (WhisperDecoding.swift:395-410): sequential fp32 cumsum, first index with cumsum >= r."""
+    c = np.cumsum(probs.astype(np.float32), dtype=np.float32)
+    i = int(np.searchsorted(c, np.float32(r), side="left"))
+    return min(i, probs.shape[0] - 1)
+
+
+def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: DecodingOptions, uniforms=None) -> DecodingResult:
+    """GreedyDecoder.decode (WhisperDecoding.swift:96-389) for ONE clip (xa [1, n_audio_ctx, D]).  temperature 0 = argmax;
+    temperature > 0 samples with `uniforms[k]` standing in for the k-th Float.random(in: 0..<1) of the reference."""
+    assert o.temperature == 0.0 or uniforms is not None, "T>0 needs explicit uniforms (the reference's RNG is unseeded)"
     V = model.dims.n_vocab
     tokens, sot_index = initial_tokens(st, o)
     init = list(tokens)
@@ -302,7 +310,13 @@ def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: 
         if force_ts:
             ts_mask[idx < tsb] = NEG
         last = last + torch.minimum(base, ts_mask)
-        nxt = int(torch.argmax(last))
+        if o.temperature == 0.0:
+            nxt = int(torch.argmax(last))
+        elif not bool(torch.isfinite(last).any()):
+            nxt = 0
+        else:
+            probs = torch.softmax(last / o.temperature, dim=-1).numpy()            # :335-338
+            nxt = sample_from_distribution(probs, float(uniforms[it]))
         top2 = torch.topk(last, 2).values
         margins.append(float(top2[0] - top2[1]))
         if nxt != st.eot:                                                # :345-350

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: Orpheus-3B (Llama-3 backbone) autoregression + SNAC decode on one MI355X, random-init bf16 weights,
+64-token prompt.  Prints one JSON line: tokens/s, fraction of the HBM roofline (6.6 GB of weights per token), SNAC samples/s."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mlx_swift_audio_amd as m
+from mlx_swift_audio_amd import codec as HC
+from mlx_swift_audio_amd import lm as HL
+from mlx_swift_audio_amd import synthetic as S
+
+name = sys.argv[1] if len(sys.argv) > 1 else "orpheus-3b"
+n_new = int(sys.argv[2]) if len(sys.argv) > 2 else 210
+cfg = S.LM_CONFIGS[name]
+ctx = m.Context(0)
+t0 = time.time()
+w = S.lm_weights(cfg, seed=0, dtype=np.float16)
+print(f"[orpheus] weights generated in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
+model = HL.CausalLM.load(ctx, cfg, w, m.BF16)
+del w
+scfg = S.SNAC_CONFIGS["snac_24khz"]
+snac = HC.SNACDecoder.load(ctx, scfg, S.snac_weights(scfg, 0))
+rng = np.random.default_rng(0)
+prompt = rng.integers(0, 128000, 64).tolist()
+u = rng.random(n_new).astype(np.float32)
+model.generate(prompt, u, max_new_tokens=16, stop_ids=(cfg.vocab - 1,))          # warm-up + graph capture
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+gen = model.generate(prompt, u, max_new_tokens=n_new, stop_ids=(cfg.vocab - 1,))
+dt = time.perf_counter() - t0
+steps = 64 + len(gen) - 1
+params = sum(int(np.prod(s)) for s in [(cfg.vocab, cfg.hidden)]) + cfg.n_layers * ((cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim * cfg.hidden +
+                                                                              cfg.hidden * cfg.n_heads * cfg.head_dim + 3 * cfg.inter * cfg.hidden)
+bytes_per_tok = 2.0 * params
+n = len(gen) // 7
+codes = [rng.integers(0, 4096, n).tolist(), rng.integers(0, 4096, 2 * n).tolist(), rng.integers(0, 4096, 4 * n).tolist()]
+noise = rng.standard_normal(snac.noise_len(4 * n)).astype(np.float32)
+snac.decode(codes, noise)
+t1 = time.perf_counter()
+pcm = snac.decode(codes, noise)
+ds = time.perf_counter() - t1
+print(json.dumps({"model": name, "prompt_tokens": 64, "generated_tokens": len(gen), "lm_steps": steps, "seconds": round(dt, 4),
+                  "tokens_per_s": round(steps / dt, 1), "ms_per_token": round(dt / steps * 1e3, 3),
+                  "weight_GB_per_token": round(bytes_per_tok / 1e9, 3), "hbm_GBs": round(bytes_per_tok * steps / dt / 1e9, 1),
+                  "hbm_frac_of_8TBs": round(bytes_per_tok * steps / dt / 8e12, 4),
+                  "snac_samples": int(pcm.size), "snac_host_inclusive_ms": round(ds * 1e3, 2),
+                  "audio_seconds_per_second_lm_only": round((len(gen) / 7 * 2048 / 24000.0) / dt, 2)}))
