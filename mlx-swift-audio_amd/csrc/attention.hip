@@ -31,9 +31,18 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(const uint16_t* _
                                                                int64_t ld_out, int T_len, int Tpad, int H, float scale_log2) {
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [2 buffers][K | V^T]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // XCD-aware mapping: the q-blocks of one (clip, head) re-read the same K / V^T; consecutive block ids are dealt round-robin to
+  // the 8 XCDs, so give every XCD a contiguous run of the linear index and keep the q-blocks of a (clip, head) adjacent in it.
+  const int nqb = (T_len + 127) / 128;                   // launch is 1-D: gridDim.x = nqb * H * B
+  int lin = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = lin % 8;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + lin / 8;
+  }
+  const int qb = lin % nqb, hb = lin / nqb;
+  const int h = hb % H, b = hb / H;
   const int D = H * 64;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = qb * 128 + wave * 32;
   const int lq = lane & 31, lh = lane >> 5;
 
   // ---- Q^T fragments (B operand): lane holds Q[q0+lq][16*ks + 8*lh + 0..7]
@@ -195,7 +204,7 @@ const char* mia_enc_attention_check(int B, int T, int H, int Tpad, int64_t ld_qk
 
 int mia_enc_attention_launch(const void* qk, int64_t ld_qk, const void* vt, void* out, int64_t ld_out, int B, int T, int H,
                              int Tpad, int dtype, hipStream_t s) {
-  dim3 grid((T + 127) / 128, H, B), block(256);
+  dim3 grid(((T + 127) / 128) * H * B), block(256);
   const float scale_log2 = 0.125f * 1.4426950408889634f;  // (64^-1/4)^2 * log2(e)
   if (dtype == MIA_F16)
     hipLaunchKernelGGL((enc_attention_kernel<F16>), grid, block, 0, s, (const uint16_t*)qk, ld_qk, (const uint16_t*)vt,

@@ -167,21 +167,24 @@ __global__ __launch_bounds__(64) void dec_skinny_gemm(SkinnyArgs a) {
   const int nb = Kc / KSTEP;
   int k = 0;
   if (nb > 0) {
-    Batch b0, b1;
+    // ring of four register batches (static names: runtime-indexed vector arrays would go to scratch): three batches of
+    // loads are always in flight behind the batch being multiplied
+    Batch b0, b1, b2, b3;
     load_batch(b0, 0);
-    int i = 0;
-    for (; i + 2 <= nb - 1; i += 2) {      // two batches per trip so both buffers keep static register names
-      load_batch(b1, (i + 1) * KSTEP);
+    if (nb > 1) load_batch(b1, KSTEP);
+    if (nb > 2) load_batch(b2, 2 * KSTEP);
+    for (int i = 0; i < nb; i += 4) {
+      if (i + 3 < nb) load_batch(b3, (i + 3) * KSTEP);
       mma_batch(b0);
-      load_batch(b0, (i + 2) * KSTEP);
+      if (i + 1 >= nb) break;
+      if (i + 4 < nb) load_batch(b0, (i + 4) * KSTEP);
       mma_batch(b1);
-    }
-    if (i + 1 <= nb - 1) {
-      load_batch(b1, (i + 1) * KSTEP);
-      mma_batch(b0);
-      mma_batch(b1);
-    } else {
-      mma_batch(b0);
+      if (i + 2 >= nb) break;
+      if (i + 5 < nb) load_batch(b1, (i + 5) * KSTEP);
+      mma_batch(b2);
+      if (i + 3 >= nb) break;
+      if (i + 6 < nb) load_batch(b2, (i + 6) * KSTEP);
+      mma_batch(b3);
     }
     k = nb * KSTEP;
   }

@@ -12,6 +12,8 @@
 // issued with W as the "A" operand, so each lane's 4 accumulator registers run along N (contiguous in C):
 // the epilogue emits 8-byte (16-bit C) or 16-byte (fp32 C) stores.
 // Workgroup ids are remapped so that the blocks sharing an XCD (and its private L2) walk neighbouring tiles.
+#include <type_traits>
+
 #include "gemm.h"
 #include "mia_device.h"
 
@@ -25,21 +27,41 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return act == MIA_ACT_GELU ? gelu_erf(v) : v;
 }
 
+// Tile order inside the contiguous block-id range an XCD receives: groups of GROUP_M row-panels walked column-major, so the
+// ~32 workgroups resident on one XCD cover ~8 row-panels x 4 column-panels and every A / W K-slice pulled into that XCD's L2 is
+// shared by 4..8 of them (row-major order re-fetched the whole W matrix for every row-panel: 9x the algorithmic bytes in
+// rocprof FETCH_SIZE for the fused QKV GEMM).
+constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_of(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int group_sz = GROUP_M * tiles_n;
+  const int gid = bid / group_sz;
+  const int first_m = gid * GROUP_M;
+  const int gm = min(tiles_m - first_m, GROUP_M);
+  const int r = bid - gid * group_sz;
+  tm = first_m + r % gm;
+  tn = r / gm;
+}
+
 __device__ __forceinline__ void glds16(const void* g, void* l) {   // async 16 B/lane HBM -> LDS (wave-uniform LDS base + lane*16)
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// One lane's 4 consecutive output columns (n .. n+3) of row m: bias, activation, residual, store in the epilogue's layout.
-template <typename T, bool OUT_F32, int EPI>
-__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int bz, int m, int n, const f32x4& a, bool vec_ok) {
-  float v[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = a[j];
+__device__ __forceinline__ f32x4 load_bias4(const GemmArgs& g, int n) {
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
   if (g.bias) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (n + j < g.N) v[j] += g.bias[n + j];
+    for (int j = 0; j < 4; ++j) if (n + j < g.N) b[j] = g.bias[n + j];
   }
+  return b;
+}
+
+// One lane's 4 consecutive output columns (n .. n+3) of row m: bias, activation, residual, store in the epilogue's layout.
+template <typename T, bool OUT_F32, int EPI>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int bz, int m, int n, const f32x4& a, const f32x4& bias4, bool vec_ok) {
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = a[j] + bias4[j];
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(v[j], g.act);
   if (g.R) {
@@ -110,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int bz = blockIdx.z;
 
@@ -213,6 +236,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   // ---- epilogue: lane holds, per (mt,nt), C[m = ..+lane&15][n = ..+(lane>>4)*4 + 0..3]
   const int e_m = lane & 15, e_n = (lane >> 4) * 4;
   const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && (g.R == nullptr || (g.ldr & 3) == 0);
+  f32x4 bias4[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) bias4[nt] = load_bias4(g, n0 + wc * 64 + nt * 16 + e_n);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = m0 + wr * 64 + mt * 16 + e_m;
@@ -221,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wc * 64 + nt * 16 + e_n;
       if (n >= g.N) continue;
-      epilogue_store<T, OUT_F32, EPI>(g, bz, m, n, acc[mt][nt], vec_ok);
+      epilogue_store<T, OUT_F32, EPI>(g, bz, m, n, acc[mt][nt], bias4[nt], vec_ok);
     }
   }
 }
@@ -248,7 +274,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256(GemmArgs g) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM2, n0 = tn * BN2;
   const int bz = blockIdx.z;
   const uint16_t* __restrict__ A = reinterpret_cast<const uint16_t*>(g.A) + (int64_t)bz * g.strideA;
@@ -282,7 +309,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256(GemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
-  auto compute = [&](int cur) {
+  // V tiles of the fused QKV GEMM are computed with the MFMA operands swapped (rows <- m): a lane's 4 accumulator registers
+  // then run along the token axis, which is the contiguous axis of the transposed V^T destination (8-byte stores instead of
+  // four scattered 2-byte ones).
+  const bool v_tile = EPI == MIA_EPI_QKV_VT && n0 >= 2 * g.H * 64;
+  auto compute = [&](int cur, auto swap_tag) {
+    constexpr bool SWAP = decltype(swap_tag)::value;
     const char* sa = lds + cur * 2 * TILE2_BYTES;
     const char* sw = sa + TILE2_BYTES;
 #pragma unroll
@@ -304,21 +336,49 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256(GemmArgs g) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) acc[mh * 4 + mt][nt] = T::mfma16(fw[nt], fa[mt], acc[mh * 4 + mt][nt]);
+          for (int nt = 0; nt < 4; ++nt)
+            acc[mh * 4 + mt][nt] = SWAP ? T::mfma16(fa[mt], fw[nt], acc[mh * 4 + mt][nt]) : T::mfma16(fw[nt], fa[mt], acc[mh * 4 + mt][nt]);
       }
     }
   };
-  int cur = 0;
-  stage_dma(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage_dma(cur ^ 1, (kt + 1) * BK);
-    compute(cur);
+  const bool diag_no_reload = g.variant == 5;          // timing-only diagnostic build path (tools/gemm_bench.py): results are wrong
+  auto main_loop = [&](auto swap_tag) {
+    int cur = 0;
+    stage_dma(0, 0);
     __syncthreads();
-    cur ^= 1;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk && !diag_no_reload) stage_dma(cur ^ 1, (kt + 1) * BK);
+      compute(cur, swap_tag);
+      __syncthreads();
+      cur ^= 1;
+    }
+  };
+  if (EPI == MIA_EPI_QKV_VT && v_tile) main_loop(std::true_type{}); else main_loop(std::false_type{});
+  if (EPI == MIA_EPI_QKV_VT && v_tile) {
+    // lane holds C[m = ..+(lane>>4)*4 + 0..3][n = ..+(lane&15)]; T % 4 == 0 keeps the 4 rows inside one clip
+    const int D2 = 2 * g.H * 64;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = m0 + wr * 128 + mt * 16 + (lane >> 4) * 4;
+      if (m >= g.M) continue;
+      const int b = m / g.T, t = m - b * g.T;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + (lane & 15);
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.f;
+        const f32x4 a = acc[mt][nt];
+        uint16_t* vt = reinterpret_cast<uint16_t*>(g.C2) + ((int64_t)b * g.H * 64 + (n - D2)) * g.Tpad + t;
+        *reinterpret_cast<u32x2*>(vt) = (u32x2){pack2<T>(a[0] + bias, a[1] + bias), pack2<T>(a[2] + bias, a[3] + bias)};
+      }
+    }
+    return;
   }
   const int e_m = lane & 15, e_n = (lane >> 4) * 4;
   const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && (g.R == nullptr || (g.ldr & 3) == 0);
+  f32x4 bias4[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) bias4[nt] = load_bias4(g, n0 + wc * 64 + nt * 16 + e_n);
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int m = m0 + wr * 128 + mt * 16 + e_m;
@@ -327,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256(GemmArgs g) {
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wc * 64 + nt * 16 + e_n;
       if (n >= g.N) continue;
-      epilogue_store<T, OUT_F32, EPI>(g, bz, m, n, acc[mt][nt], vec_ok);
+      epilogue_store<T, OUT_F32, EPI>(g, bz, m, n, acc[mt][nt], bias4[nt], vec_ok);
     }
   }
 }
@@ -369,7 +429,7 @@ template <typename T>
 int launch_t(const GemmArgs& g, hipStream_t s) {
   if (g.variant == 0) return launch_ts<T, 0>(g, s);
   if (g.variant == 1) return launch_ts<T, 1>(g, s);
-  if (g.variant == 2) return launch_256<T>(g, s);
+  if (g.variant == 2 || g.variant == 5) return launch_256<T>(g, s);
   // auto: the 256^2 tile needs enough tiles to fill 256 CUs; small problems keep the 128^2 tile
   const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.batch > 0 ? g.batch : 1);
   return tiles256 >= 256 ? launch_256<T>(g, s) : launch_ts<T, 1>(g, s);
@@ -387,7 +447,7 @@ const char* mia_gemm_check(const GemmArgs& g) {
     if (g.out_f32) return "gemm: special epilogues emit 16-bit output only";
     if (g.T <= 0 || g.H <= 0) return "gemm: special epilogue needs T and H";
     if (g.batch > 1) return "gemm: special epilogues use the flattened M = B*T form";
-    if (g.epi == MIA_EPI_QKV_VT && (g.N != 3 * g.H * 64 || g.ldc % 4 != 0 || g.Tpad < g.T || !g.C2)) return "gemm: bad QKV_VT arguments";
+    if (g.epi == MIA_EPI_QKV_VT && (g.N != 3 * g.H * 64 || g.ldc % 4 != 0 || g.Tpad < g.T || !g.C2 || g.T % 4 != 0 || g.Tpad % 4 != 0)) return "gemm: bad QKV_VT arguments";
     if (g.epi == MIA_EPI_HEADMAJOR && g.N != g.H * 64) return "gemm: HEADMAJOR needs N == H*64";
   }
   return nullptr;

@@ -11,7 +11,8 @@
 namespace {
 
 int gemm(mia_whisper* w, GemmArgs g, int cls = MIA_PROF_ENC_GEMM) {
-  static const int forced = getenv("MIA_GEMM_VARIANT") ? atoi(getenv("MIA_GEMM_VARIANT")) : -1;
+  const char* fv = getenv("MIA_GEMM_VARIANT");   // test hook: force a tile variant (0/1: 128^2, 2: 256^2)
+  const int forced = fv ? atoi(fv) : -1;
   if (forced >= 0) g.variant = forced;
   if (const char* e = mia_gemm_check(g)) return mia_fail(w->ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
   const int rec = mia_prof_begin(w->ctx, cls, 2.0 * g.M * (double)g.N * g.K * (g.batch > 0 ? g.batch : 1));

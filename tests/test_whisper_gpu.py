@@ -52,6 +52,20 @@ def test_encoder_matches_oracle(ctx, dims_name, dtype_name):
     model.close()
 
 
+@pytest.mark.parametrize("variant", ["0", "2"])
+def test_encoder_forced_tile_variants(ctx, variant, monkeypatch):
+    """The 256^2 tile (and its operand-swapped V path) is only auto-selected at full size: force it on the reduced model."""
+    monkeypatch.setenv("MIA_GEMM_VARIANT", variant)
+    dims, oracle, model = _models(ctx, "micro", "f16", seed=6)
+    mel = _mel(dims, 5, 2, "f16")
+    model.encode(mel)
+    got = model.audio_features()
+    ref = oracle.encode(mel).numpy()
+    err = np.abs(got - ref)
+    assert err.max() <= 0.01 and err.mean() <= 0.0015, (err.max(), err.mean())
+    model.close()
+
+
 def _compare(tokens, ref, tol):
     n = min(len(tokens), len(ref.tokens))
     for i in range(n):
