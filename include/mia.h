@@ -30,6 +30,7 @@ typedef struct mia_ctx mia_ctx;
 typedef struct mia_whisper mia_whisper;
 typedef struct mia_codec mia_codec;
 typedef struct mia_lm mia_lm;
+typedef struct mia_s3tok mia_s3tok;
 
 typedef enum {
   MIA_OK = 0,
@@ -252,6 +253,20 @@ int mia_lm_generate(mia_lm* lm, const int32_t* prompt, int n_prompt, const mia_l
 /* One sampleNextToken call on caller-provided logits (host pointers). */
 int mia_sample_top_p(mia_ctx* ctx, const float* logits, int V, const int32_t* history, int n_hist, float rep_penalty,
                      float temperature, float top_p, float uniform, int32_t* out);
+
+/* ---- S3Tokenizer (speech -> 25 Hz token ids) ---------------------------------------------------- */
+/* S3TokenizerModelConfig / V3 (Codec/S3Tokenizer/S3TokenizerConfig.swift:9-90): V2 = 6 blocks, V3 = 12. */
+typedef struct { int32_t n_mels, n_audio_state, n_audio_head, n_audio_layer; } mia_s3_config;
+/* float32 tensors, Module key schema of the reference: encoder.conv{1,2}.{weight,bias}, encoder.blocks.N.attn.{query,key,value,out}.*,
+ * encoder.blocks.N.attn.fsmn_block.weight, encoder.blocks.N.{attn_ln,mlp_ln}.*, encoder.blocks.N.mlp.layers.{0,2}.*,
+ * quantizer.fsq_codebook.project_down.{weight,bias}. */
+mia_s3tok* mia_s3tok_load(mia_ctx* ctx, const mia_s3_config* cfg, const mia_tensor_view* tensors, int n_tensors);
+void mia_s3tok_free(mia_s3tok* s3);
+/* Replaces S3TokenizerV2.quantize(mel:melLen:) for clips of at most 30 s (Codec/S3Tokenizer/S3Tokenizer.swift:474-494; called at
+ * TTS/CosyVoice2/CosyVoice2TTS.swift:391).  mel float32 [B][n_mels][T] (the layout mia_logmel_s3 emits), mel_len / tok_len host
+ * int32 [B]; tokens int32 [B][tokens_stride], zero padded; token count = ((len-1)/2+1 - 1)/2 + 1. */
+int mia_s3tok_encode(mia_s3tok* s3, const float* mel, const int32_t* mel_len, int B, int T, int32_t* tokens, int tokens_stride,
+                     int32_t* tok_len, int mem);
 
 #ifdef __cplusplus
 }

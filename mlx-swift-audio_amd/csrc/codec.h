@@ -18,6 +18,9 @@ struct ConvGemmArgs {
   const float* noise = nullptr;        // if set: Y = R + noise[row] * (acc + bias)
   int M = 0, N = 0, Cin = 0, taps = 1, dil = 1, pad = 0;
   int tanh_out = 0;
+  int x_row_mul = 1;                   // convolution stride: A(m, tap, c) = X[m*x_row_mul + tap*dil - pad][c]
+  int gelu = 0;                        // exact-erf GELU on acc + bias (before the residual)
+  int64_t ldw = 0;                     // row stride of W (0 = taps*Cin, i.e. dense)
 };
 
 constexpr int MIA_MAX_LEVELS = 4;

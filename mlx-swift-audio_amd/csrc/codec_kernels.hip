@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   const int z = blockIdx.z;
   const float* __restrict__ W = g.W + (int64_t)z * g.w_phase_stride;
   const int Ktot = g.taps * g.Cin;
+  const int64_t ldw = g.ldw > 0 ? g.ldw : Ktot;
 
   // staging coordinates: A: 4 rows x float4 per thread, B: WN*2 rows x float4 per thread
   const int s_row = tid >> 3, s_col = (tid & 7) * 4;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + s_row + 32 * i;
-      const int64_t xr = (int64_t)m + (int64_t)tap * g.dil - g.pad;
+      const int64_t xr = (int64_t)m * g.x_row_mul + (int64_t)tap * g.dil - g.pad;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < g.M && xr >= 0 && xr < g.T_in) {
         v = *reinterpret_cast<const float4*>(g.X + xr * g.ldx + c0);
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2 * WN; ++i) {
       const int n = n0 + s_row + 32 * i;
-      rb[i] = n < g.N ? *reinterpret_cast<const float4*>(W + (int64_t)n * Ktot + k0 + s_col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = n < g.N ? *reinterpret_cast<const float4*>(W + (int64_t)n * ldw + k0 + s_col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_tiles = [&]() {
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
         const int64_t yr = (int64_t)m * g.y_row_mul + g.y_row_off + (int64_t)z * g.y_phase_step;
         if (yr < 0 || yr >= g.T_out) continue;
         float v = acc[i][j][r] + bias;
+        if (g.gelu) v = gelu_erf(v);
         if (g.noise) v = g.R[yr * g.ldr + n] + g.noise[yr] * v;
         else if (g.R) v += g.R[yr * g.ldr + n];
         if (g.tanh_out) v = tanhf(v);

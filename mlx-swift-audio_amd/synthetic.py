@@ -338,3 +338,46 @@ def lm_weights(cfg: LMConfig, seed: int = 0, round_to: str | None = None, dtype=
         mat(p + ".mlp.up_proj.weight", cfg.inter, D)
         mat(p + ".mlp.down_proj.weight", D, cfg.inter)
     return w
+
+
+# ---- S3Tokenizer --------------------------------------------------------------------------------------------------
+@dataclass
+class S3Config:
+    """S3TokenizerModelConfig (S3TokenizerConfig.swift:9-50); V3 = 12 layers."""
+    n_mels: int = 128
+    n_audio_state: int = 1280
+    n_audio_head: int = 20
+    n_audio_layer: int = 6
+
+
+S3_CONFIGS = {"s3_v2": S3Config(), "s3_v3": S3Config(n_audio_layer=12), "s3_micro": S3Config(128, 128, 2, 2)}
+
+
+def s3_weights(cfg: S3Config, seed: int = 0) -> dict[str, np.ndarray]:
+    """Random-init S3Tokenizer tensors with the reference's Module key paths (S3Tokenizer.swift)."""
+    w: dict[str, np.ndarray] = {}
+    D, M = cfg.n_audio_state, cfg.n_mels
+
+    def t(name, shape, std):
+        rng = np.random.Generator(np.random.PCG64(_key_seed(name, seed)))
+        w[name] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+    def ln(p):
+        t(p + ".weight", (D,), 0.1); w[p + ".weight"] += 1.0
+        t(p + ".bias", (D,), 0.1)
+
+    t("encoder.conv1.weight", (D, 3, M), 1.0 / math.sqrt(3 * M)); t("encoder.conv1.bias", (D,), 0.1)
+    t("encoder.conv2.weight", (D, 3, D), 1.0 / math.sqrt(3 * D)); t("encoder.conv2.bias", (D,), 0.1)
+    for l in range(cfg.n_audio_layer):
+        p = f"encoder.blocks.{l}"
+        ln(p + ".attn_ln"); ln(p + ".mlp_ln")
+        for nm, bias in (("query", True), ("key", False), ("value", True), ("out", True)):
+            t(f"{p}.attn.{nm}.weight", (D, D), 1.0 / math.sqrt(D))
+            if bias:
+                t(f"{p}.attn.{nm}.bias", (D,), 0.1)
+        t(p + ".attn.fsmn_block.weight", (D, 31, 1), 1.0 / math.sqrt(31))
+        t(p + ".mlp.layers.0.weight", (4 * D, D), 1.0 / math.sqrt(D)); t(p + ".mlp.layers.0.bias", (4 * D,), 0.1)
+        t(p + ".mlp.layers.2.weight", (D, 4 * D), 1.0 / math.sqrt(4 * D)); t(p + ".mlp.layers.2.bias", (D,), 0.1)
+    t("quantizer.fsq_codebook.project_down.weight", (8, D), 1.0 / math.sqrt(D))
+    t("quantizer.fsq_codebook.project_down.bias", (8,), 0.1)
+    return w
