@@ -250,6 +250,15 @@ int mia_lm_forward(mia_lm* lm, const int32_t* ids, int n, float* last_logits);
  * over the kept tokens in index order).  Host pointers. */
 int mia_lm_generate(mia_lm* lm, const int32_t* prompt, int n_prompt, const mia_lm_sampler* sampler, const float* uniforms,
                     int32_t* out_tokens, int32_t* n_out);
+/* CosyVoice2 RAS sampling parameters (TTS/CosyVoice2/LLM/Qwen2LM.swift:433-488 defaults: top_p 0.8, top_k 25, win 10, tau 0.1;
+ * eos = speech_token_size (6561); min_len / max_len = 2x / 20x the text length, :368-372). */
+typedef struct { float top_p; int32_t top_k; int32_t win; float tau; int32_t eos; int32_t min_len; int32_t max_len; } mia_ras_params;
+/* Qwen2LM.inference + inferenceLoop (Qwen2LM.swift:335-427) on device.  The model must have been loaded with the extra
+ * tensors llm_decoder.{weight,bias} and speech_embedding.weight.  prompt_embeds: float32 [n_prompt][hidden] =
+ * [llm_embedding[sos], embed_tokens(prompt_text + text), llm_embedding[task], speech_embedding(prompt tokens)], gathered by
+ * the caller.  uniforms: the stream of explicit draws (one per categorical; rejected EOS trials consume more).  Host pointers. */
+int mia_lm_generate_ras(mia_lm* lm, const float* prompt_embeds, int n_prompt, const mia_ras_params* rp, const float* uniforms,
+                        int n_uniforms, int32_t* out_tokens, int32_t* n_out);
 /* One sampleNextToken call on caller-provided logits (host pointers). */
 int mia_sample_top_p(mia_ctx* ctx, const float* logits, int V, const int32_t* history, int n_hist, float rep_penalty,
                      float temperature, float top_p, float uniform, int32_t* out);

@@ -19,7 +19,7 @@
 
 #include "decode.h"
 
-struct LmState { int pos; int n_hist; int finished; int n_gen; };
+struct LmState { int pos; int n_hist; int finished; int n_gen; int n_embeds; int n_out; int u_cursor; int pad; };
 
 struct LmLayer {
   float* in_norm = nullptr; float* post_norm = nullptr;
@@ -36,6 +36,12 @@ struct mia_lm {
   std::vector<void*> allocs;
   void* embed = nullptr;        // 16-bit [V][hidden]
   void* lm_head = nullptr;      // 16-bit [V][hidden] (== embed when tied)
+  float* head_bias = nullptr;   // optional (CosyVoice2 llm_decoder)
+  int head_vocab = 0;           // rows of lm_head (CosyVoice2: speech vocabulary + 3)
+  void* gen_embed = nullptr;    // 16-bit [rows][hidden]: embedding of GENERATED ids when it differs from embed (speech_embedding)
+  int gen_rows = 0;
+  float* embeds = nullptr;      // fp32 [max_ctx][hidden]: caller-provided prompt embeddings (Qwen2LM.inference builds its prompt from three tables)
+  int32_t* out_tokens = nullptr;  // [max_ctx] emitted tokens of the RAS loop
   float* final_norm = nullptr;
   float* inv_freq = nullptr;    // [dh/2]
   std::vector<LmLayer> layers;
@@ -85,20 +91,27 @@ __device__ __forceinline__ void rms_store(const f32x4 (&v)[LM_NV], int nv, int D
 
 // x = E[token[pos]] (or a caller-provided embedding row);  h = RMSNorm(x) * w
 template <typename T>
-__global__ __launch_bounds__(256) void lm_embed_norm(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ emb, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void lm_embed_norm(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ emb, const uint16_t* __restrict__ gen_emb,
+                                                     const float* __restrict__ embeds, const float* __restrict__ w,
                                                      float* __restrict__ x, uint16_t* __restrict__ h, const LmState* __restrict__ st, int D, float eps) {
   __shared__ float sh[4];
   const int tid = threadIdx.x, nv = D >> 2;
-  const int tok = tokens[st->pos];
-  const uint16_t* e = emb + (int64_t)tok * D;
+  const int pos = st->pos;
+  const bool from_rows = pos < st->n_embeds;               // prompt given as embedding rows
+  const int tok = from_rows ? 0 : tokens[pos];
+  const uint16_t* e = ((st->n_embeds > 0 && gen_emb) ? gen_emb : emb) + (int64_t)tok * D;
+  const float* er = embeds + (int64_t)pos * D;
   f32x4 v[LM_NV];
 #pragma unroll
   for (int i = 0; i < LM_NV; ++i) {
     const int c = tid + 256 * i;
     if (c < nv) {
-      const s16x4 ev = *reinterpret_cast<const s16x4*>(e + 4 * c);
+      if (from_rows) v[i] = *reinterpret_cast<const f32x4*>(er + 4 * c);
+      else {
+        const s16x4 ev = *reinterpret_cast<const s16x4*>(e + 4 * c);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[i][j] = T::to_f32((uint16_t)ev[j]);
+        for (int j = 0; j < 4; ++j) v[i][j] = T::to_f32((uint16_t)ev[j]);
+      }
       *reinterpret_cast<f32x4*>(x + 4 * c) = v[i];
     } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -425,6 +438,134 @@ __global__ __launch_bounds__(1024) void lm_sample(float* __restrict__ logits, in
   }
 }
 
+// ---- RAS sampler of CosyVoice2 (Qwen2LM.swift:295-321, 433-488): nucleus (top-p 0.8 capped at top-k 25, renormalised, drawn in
+// descending-probability order); if the pick already occurs >= win*tau times among the last `win` emitted tokens, redraw from the
+// full softmax; while i < min_len an EOS pick is rejected and the whole trial repeated (<= 100 times).  Every categorical draw is
+// an inverse CDF with the next caller-provided uniform (u_cursor walks the stream).
+struct RasParams { float top_p; int top_k; int win; float tau; int eos; int min_len; int max_len; int n_uniforms; };
+
+__global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ logits, int V, int32_t* __restrict__ tokens, int32_t* __restrict__ out_tokens,
+                                                      const float* __restrict__ uniforms, LmState* __restrict__ st, RasParams rp, int max_ctx) {
+  __shared__ float sh[16];
+  __shared__ int shi[16];
+  __shared__ float topv[32];
+  __shared__ int topi[32];
+  __shared__ int s_tok[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pos = st->pos, n_prompt = st->n_embeds;
+  const int cur_len = pos + 1;
+  if (cur_len < n_prompt || st->finished) { __syncthreads(); if (tid == 0 && !st->finished) st->pos = pos + 1; return; }
+  const int step_i = cur_len - n_prompt;                 // loop index i of inferenceLoop
+  // softmax statistics
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, logits[i]);
+  mx = blk1024_max(mx, sh);
+  float tot = 0.f;
+  for (int i = tid; i < V; i += 1024) tot += __expf(logits[i] - mx);
+  tot = blk1024_sum(tot, sh);
+  // top-k by iterated block argmax (k <= 32): (value, index) with lowest index on ties; previously taken entries are skipped
+  const int K = rp.top_k < 32 ? rp.top_k : 32;
+  for (int r = 0; r < K; ++r) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 1024) {
+      const float v = logits[i];
+      bool taken = false;
+      for (int q = 0; q < r; ++q) taken = taken || topi[q] == i;
+      if (!taken && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sh[wave] = bv; shi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float v = sh[0]; int ix = shi[0];
+      for (int w2 = 1; w2 < 16; ++w2) if (sh[w2] > v || (sh[w2] == v && shi[w2] < ix)) { v = sh[w2]; ix = shi[w2]; }
+      topv[r] = __expf(v - mx) / tot; topi[r] = ix;
+    }
+    __syncthreads();
+  }
+  // per-wave partial sums of the full softmax in index order (for the fallback draw)
+  const int per_wave = (V + 15) / 16;
+  const int w_lo = wave * per_wave, w_hi = min(V, w_lo + per_wave);
+  float wsum = 0.f;
+  for (int i = w_lo + lane; i < w_hi; i += 64) wsum += __expf(logits[i] - mx);
+  wsum = wave_sum(wsum);
+  __shared__ float wtot[16];
+  if (lane == 0) wtot[wave] = wsum;
+  __syncthreads();
+  __shared__ int s_need_full; __shared__ float s_goal; __shared__ int s_sel; __shared__ float s_cum;
+  int trials = 0;
+  int pick = -1;
+  while (true) {                                         // trial loop (uniform across the block through shared state)
+    if (tid == 0) {
+      int cur = st->u_cursor;
+      // nucleus: n = min(count(cumsum < top_p) + 1, top_k)
+      float cum = 0.f; int below = 0;
+      for (int r = 0; r < K; ++r) { cum += topv[r]; if (cum < rp.top_p) ++below; }
+      int n = below + 1; if (n > K) n = K;
+      float ns = 0.f;
+      for (int r = 0; r < n; ++r) ns += topv[r];
+      const float u = uniforms[cur < rp.n_uniforms ? cur : rp.n_uniforms - 1]; ++cur;
+      float c2 = 0.f; int sel = n - 1;
+      for (int r = 0; r < n; ++r) { c2 += topv[r]; if (c2 > u * ns) { sel = r; break; } }
+      int tok = topi[sel];
+      // repetition-aware fallback (rasSampling :463-488): over the last `win` EMITTED tokens
+      int rep = 0; const int no = st->n_out;
+      for (int q = max(0, no - rp.win); q < no; ++q) rep += out_tokens[q] == tok;
+      int need_full = 0;
+      if (no > 0 && (float)rep >= (float)rp.win * rp.tau) {
+        need_full = 1;
+        const float u2 = uniforms[cur < rp.n_uniforms ? cur : rp.n_uniforms - 1]; ++cur;
+        const float goal = u2 * tot;
+        float c3 = 0.f; int ws = 15;
+        for (int w2 = 0; w2 < 16; ++w2) { if (c3 + wtot[w2] > goal) { ws = w2; break; } c3 += wtot[w2]; }
+        s_goal = goal; s_sel = ws; s_cum = c3;
+      }
+      st->u_cursor = cur;
+      s_need_full = need_full; s_tok[0] = tok;
+    }
+    __syncthreads();
+    if (s_need_full) {
+      if (wave == s_sel) {                               // ordered scan of the selected index range
+        float cum = s_cum; int found = -1;
+        for (int base = w_lo; base < w_hi && found < 0; base += 64) {
+          const int i = base + lane;
+          const float p = i < w_hi ? __expf(logits[i] - mx) : 0.f;
+          float incl = p;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+          const unsigned long long hit = __ballot(p > 0.f && cum + incl > s_goal);
+          if (hit) found = base + (__ffsll((long long)hit) - 1);
+          cum += __shfl(incl, 63, 64);
+        }
+        if (found < 0) found = w_hi - 1;
+        if (lane == 0) s_tok[0] = found;
+      }
+      __syncthreads();
+    }
+    pick = s_tok[0];
+    ++trials;
+    const bool ignore_eos = step_i < rp.min_len;
+    if (!(ignore_eos && pick == rp.eos) || trials > 100) break;   // the Swift throws after 100 rejected trials; we keep the EOS
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int ng = st->n_gen;
+    st->n_gen = ng + 1;
+    if (pick == rp.eos) st->finished = 1;
+    else {
+      if (cur_len < max_ctx) tokens[cur_len] = pick;     // embedding input of the next step (speech_embedding[pick])
+      if (pick < rp.eos) { out_tokens[st->n_out] = pick; st->n_out += 1; }   // ids above EOS (fill tokens) are fed back, not emitted
+      if (step_i + 1 >= rp.max_len || cur_len + 1 >= max_ctx) st->finished = 1;
+      st->pos = pos + 1;
+    }
+  }
+}
+
 // greedy / plain path: advance only (logits are read back by the host)
 __global__ void lm_advance(LmState* st) { st->pos += 1; }
 
@@ -474,7 +615,7 @@ struct LmLoader {
 
 int pick_split(int K, int want) { for (int s = want; s > 1; --s) if (K % (32 * s) == 0) return s; return 1; }
 
-int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_prompt) {
+int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_prompt, const RasParams* ras = nullptr) {
   hipStream_t s = m->ctx->stream;
   const mia_lm_config& c = m->cfg;
   const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh, Nqkv = Nq + 2 * Nk;
@@ -484,7 +625,7 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
     return skinny_gemm_launch(a, mode, m->dtype, s);
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
-  LAUNCH_T(lm_embed_norm, dim3(1), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps);
+  LAUNCH_T(lm_embed_norm, dim3(1), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps);
   const size_t att_lds = (size_t)(c.max_ctx + 4 * dh + 8) * 4;
   for (int l = 0; l < c.n_layers; ++l) {
     const LmLayer& L = m->layers[l];
@@ -509,8 +650,10 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
     LAUNCH_T(lm_reduce_norm, dim3(1), dim3(256), 0, m->partial, m->S_down, l + 1 < c.n_layers ? m->layers[l + 1].in_norm : m->final_norm, m->x, (uint16_t*)m->h, D, c.rms_eps);
   }
 #undef LAUNCH_T
-  if (skinny(m->h, D, m->lm_head, nullptr, m->logits, c.vocab, c.vocab, D, 1, SK_OUTF32)) return -1;
-  if (sampling) hipLaunchKernelGGL(lm_sample, dim3(1), dim3(1024), 0, s, m->logits, c.vocab, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx);
+  const int HV = m->head_vocab > 0 ? m->head_vocab : c.vocab;
+  if (skinny(m->h, D, m->lm_head, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32)) return -1;
+  if (ras) hipLaunchKernelGGL(lm_sample_ras, dim3(1), dim3(1024), 0, s, m->logits, HV, m->tokens, m->out_tokens, m->uniforms, m->state, *ras, c.max_ctx);
+  else if (sampling) hipLaunchKernelGGL(lm_sample, dim3(1), dim3(1024), 0, s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx);
   else hipLaunchKernelGGL(lm_advance, dim3(1), dim3(1), 0, s, m->state);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -563,8 +706,19 @@ extern "C" mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia
   std::vector<float> t, t2, t3;
   if (L.to_f32("model.embed_tokens.weight", t, c.vocab, D)) m->embed = L.up16(t);
   if (c.tie_embeddings) m->lm_head = m->embed;
-  else if (L.to_f32("lm_head.weight", t, c.vocab, D)) m->lm_head = L.up16(t);
+  else if (L.find("lm_head.weight", false) && L.to_f32("lm_head.weight", t, c.vocab, D)) m->lm_head = L.up16(t);
   if (L.to_f32("model.norm.weight", t, D, 0)) m->final_norm = L.up32(t);
+  if (const mia_tensor_view* hv = L.find("llm_decoder.weight", false)) {      // Qwen2LM: separate output head + speech embedding
+    if (hv->ndim == 2 && hv->shape[1] == D) {
+      m->head_vocab = (int)hv->shape[0];
+      if (L.to_f32("llm_decoder.weight", t, m->head_vocab, D)) m->lm_head = L.up16(t);
+      if (L.find("llm_decoder.bias", false) && L.to_f32("llm_decoder.bias", t, m->head_vocab, 0)) m->head_bias = L.up32(t);
+    } else L.err = "llm_decoder.weight has an unexpected shape";
+  }
+  if (const mia_tensor_view* gv = L.find("speech_embedding.weight", false)) {
+    if (gv->ndim == 2 && gv->shape[1] == D) { m->gen_rows = (int)gv->shape[0]; if (L.to_f32("speech_embedding.weight", t, m->gen_rows, D)) m->gen_embed = L.up16(t); }
+    else L.err = "speech_embedding.weight has an unexpected shape";
+  }
   {  // rotary inverse frequencies: plain RoPE(base) or Llama3RoPE (Llama3RoPE.swift:41-65: period-like `freqs`, MLX divides positions by them)
     std::vector<float> inv(dh / 2);
     for (int i = 0; i < dh / 2; ++i) {
@@ -615,9 +769,10 @@ extern "C" mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia
   m->k_cache = L.dev(kv); m->v_cache = L.dev(kv);
   m->x = (float*)L.dev((size_t)D * 4); m->h = L.dev((size_t)D * 2);
   m->qkv_part = (float*)L.dev((size_t)4 * (Nq + 2 * Nk) * 4); m->q = L.dev((size_t)Nq * 2); m->att = L.dev((size_t)Nq * 2); m->act = L.dev((size_t)c.inter * 2);
-  m->partial = (float*)L.dev((size_t)8 * D * 4); m->logits = (float*)L.dev((size_t)c.vocab * 4);
+  m->partial = (float*)L.dev((size_t)8 * D * 4); m->logits = (float*)L.dev((size_t)std::max(c.vocab, m->head_vocab) * 4);
   m->tokens = (int32_t*)L.dev((size_t)c.max_ctx * 4); m->hist = (int32_t*)L.dev(64 * 4); m->uniforms = (float*)L.dev((size_t)c.max_ctx * 4);
   m->state = (LmState*)L.dev(sizeof(LmState));
+  m->embeds = (float*)L.dev((size_t)c.max_ctx * D * 4); m->out_tokens = (int32_t*)L.dev((size_t)c.max_ctx * 4);
   if (!L.err.empty()) return fail(m, L.err);
   (void)hipMemset(m->k_cache, 0, kv); (void)hipMemset(m->v_cache, 0, kv); (void)hipMemset(m->state, 0, sizeof(LmState));
   if (hipDeviceSynchronize() != hipSuccess) return fail(m, "device error during upload");
@@ -717,6 +872,44 @@ extern "C" int mia_sample_top_p(mia_ctx* ctx, const float* logits, int V, const 
   hipLaunchKernelGGL(lm_sample, dim3(1), dim3(1024), 0, s, d_logits, V, d_tok, d_hist, d_u, d_st, sp, 1, 2);
   MIA_HIP(ctx, hipGetLastError());
   MIA_HIP(ctx, hipMemcpyAsync(out, d_tok + 1, 4, hipMemcpyDeviceToHost, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  return MIA_OK;
+}
+
+// Qwen2LM.inference / inferenceLoop (TTS/CosyVoice2/LLM/Qwen2LM.swift:335-427) on device: prompt given as embedding rows
+// [sos, text..., task, prompt speech...] (the caller gathers them from its three tables), generated ids embedded through
+// speech_embedding, logits through llm_decoder, RAS sampling with explicit uniforms.
+extern "C" int mia_lm_generate_ras(mia_lm* m, const float* prompt_embeds, int n_prompt, const mia_ras_params* rp, const float* uniforms, int n_uniforms,
+                                   int32_t* out_tokens, int32_t* n_out) {
+  if (!m) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = m->ctx;
+  MIA_CHECK_ARG(ctx, prompt_embeds && n_prompt > 0 && rp && uniforms && n_uniforms > 0 && out_tokens && n_out, "lm_generate_ras: null arguments");
+  MIA_CHECK_ARG(ctx, m->gen_embed && m->head_vocab > 0, "lm_generate_ras: model has no speech_embedding / llm_decoder tensors");
+  MIA_CHECK_ARG(ctx, rp->max_len > 0 && n_prompt + rp->max_len <= m->cfg.max_ctx, "lm_generate_ras: prompt + max_len exceeds max_ctx");
+  MIA_CHECK_ARG(ctx, rp->top_k > 0 && rp->top_k <= 32 && rp->win >= 0 && rp->win <= 64 && rp->eos >= 0 && rp->eos < m->head_vocab, "lm_generate_ras: bad sampler parameters");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  LmState st{}; st.n_embeds = n_prompt;
+  MIA_HIP(ctx, hipMemcpyAsync(m->state, &st, sizeof(st), hipMemcpyHostToDevice, s));
+  MIA_HIP(ctx, hipMemcpyAsync(m->embeds, prompt_embeds, (size_t)n_prompt * m->cfg.hidden * 4, hipMemcpyHostToDevice, s));
+  const int nu = std::min(n_uniforms, m->cfg.max_ctx);
+  MIA_HIP(ctx, hipMemcpyAsync(m->uniforms, uniforms, (size_t)nu * 4, hipMemcpyHostToDevice, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  RasParams r{rp->top_p, rp->top_k, rp->win, rp->tau, rp->eos, rp->min_len, rp->max_len, nu};
+  mia_lm_sampler none{};
+  const int total = n_prompt + rp->max_len - 1;
+  for (int step = 0; step < total; ++step) {
+    if (lm_enqueue_step(m, true, none, n_prompt, &r)) return mia_fail(ctx, MIA_ERR_DEVICE, "lm_generate_ras: launch failed");
+    if (step >= n_prompt && (step & 15) == 15) {
+      MIA_HIP(ctx, hipMemcpyAsync(&st, m->state, sizeof(st), hipMemcpyDeviceToHost, s));
+      MIA_HIP(ctx, hipStreamSynchronize(s));
+      if (st.finished) break;
+    }
+  }
+  MIA_HIP(ctx, hipMemcpyAsync(&st, m->state, sizeof(st), hipMemcpyDeviceToHost, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  *n_out = st.n_out;
+  MIA_HIP(ctx, hipMemcpyAsync(out_tokens, m->out_tokens, (size_t)st.n_out * 4, hipMemcpyDeviceToHost, s));
   MIA_HIP(ctx, hipStreamSynchronize(s));
   return MIA_OK;
 }

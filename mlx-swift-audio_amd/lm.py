@@ -131,6 +131,49 @@ def parse_output(tokens: list[int]) -> list[list[int]]:
     return [l1, l2, l3]
 
 
+class _Ras(C.Structure):
+    _fields_ = [("top_p", C.c_float), ("top_k", C.c_int32), ("win", C.c_int32), ("tau", C.c_float), ("eos", C.c_int32),
+                ("min_len", C.c_int32), ("max_len", C.c_int32)]
+
+
+class Qwen2LM:
+    """Qwen2LM.inference (TTS/CosyVoice2/LLM/Qwen2LM.swift:335-376): the prompt is assembled from three embedding tables on the
+    host (row gathers, no arithmetic) and handed to the device loop as embedding rows."""
+
+    SOS_EOS, TASK_ID = 0, 1
+
+    def __init__(self, lm: CausalLM, weights: dict[str, np.ndarray], speech_token_size: int = 6561):
+        self.lm, self.speech_token_size = lm, speech_token_size
+        self.text_emb = weights["model.embed_tokens.weight"]
+        self.llm_emb = weights["llm_embedding.weight"]
+        self.speech_emb = weights["speech_embedding.weight"]
+
+    def lm_input(self, text, prompt_text, prompt_speech_tokens) -> np.ndarray:
+        from .synthetic import round_array
+        rows = [self.llm_emb[self.SOS_EOS][None], self.text_emb[np.asarray(list(prompt_text) + list(text), np.int64)],
+                self.llm_emb[self.TASK_ID][None]]
+        if len(prompt_speech_tokens):
+            rows.append(self.speech_emb[np.asarray(prompt_speech_tokens, np.int64)])
+        return np.ascontiguousarray(np.concatenate(rows, axis=0), np.float32)
+
+    def inference(self, text, prompt_text, prompt_speech_tokens, uniforms, max_token_text_ratio=20.0, min_token_text_ratio=2.0,
+                  top_p=0.8, top_k=25, win=10, tau=0.1) -> list[int]:
+        x = self.lm_input(text, prompt_text, prompt_speech_tokens)
+        min_len, max_len = int(len(text) * min_token_text_ratio), int(len(text) * max_token_text_ratio)
+        _declare(self.lm.ctx.lib)
+        lib = self.lm.ctx.lib
+        if not getattr(lib, "_ras_declared", False):
+            lib.mia_lm_generate_ras.restype = C.c_int
+            lib.mia_lm_generate_ras.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Ras), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+            lib._ras_declared = True
+        rp = _Ras(top_p, top_k, win, tau, self.speech_token_size, min_len, max_len)
+        u = np.ascontiguousarray(uniforms, np.float32)
+        out = np.zeros(max_len + 1, np.int32)
+        n = C.c_int32(0)
+        self.lm.ctx.check(lib.mia_lm_generate_ras(self.lm.h, x.ctypes.data, x.shape[0], C.byref(rp), u.ctypes.data, u.size, out.ctypes.data, C.byref(n)))
+        return out[:n.value].tolist()
+
+
 class OrpheusTTS:
     """generateChunk (TTS/Orpheus/TTSEngine/OrpheusTTS.swift:224-373) from token ids onward: LM sampling loop ->
     parseOutput -> SNAC decode.  Text tokenisation / voice prefix / sentence splitting stay with the caller (CPU text code)."""

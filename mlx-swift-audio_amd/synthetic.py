@@ -381,3 +381,16 @@ def s3_weights(cfg: S3Config, seed: int = 0) -> dict[str, np.ndarray]:
     t("quantizer.fsq_codebook.project_down.weight", (8, D), 1.0 / math.sqrt(D))
     t("quantizer.fsq_codebook.project_down.bias", (8,), 0.1)
     return w
+
+
+def qwen2lm_extra_weights(cfg: LMConfig, speech_token_size: int = 6561, seed: int = 0, round_to: str | None = None) -> dict[str, np.ndarray]:
+    """The three CosyVoice2 tensors around the Qwen2 backbone (Qwen2LM.swift:259-263): llm_embedding [2,h], llm_decoder [S+3,h](+bias),
+    speech_embedding [S+3,h]."""
+    w = {}
+    rng = np.random.Generator(np.random.PCG64(seed + 4242))
+    h = cfg.hidden
+    w["llm_embedding.weight"] = round_array(rng.standard_normal((2, h), dtype=np.float32) * np.float32(1.0 / math.sqrt(h) * 3.0), round_to)
+    w["speech_embedding.weight"] = round_array(rng.standard_normal((speech_token_size + 3, h), dtype=np.float32) * np.float32(1.0 / math.sqrt(h) * 3.0), round_to)
+    w["llm_decoder.weight"] = round_array(rng.standard_normal((speech_token_size + 3, h), dtype=np.float32) * np.float32(1.0 / math.sqrt(h) * 4.0), round_to)
+    w["llm_decoder.bias"] = (0.1 * rng.standard_normal(speech_token_size + 3)).astype(np.float32)
+    return w

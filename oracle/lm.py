@@ -66,10 +66,15 @@ class LMOracle:
 
     def forward(self, ids) -> torch.Tensor:
         """model(ids, cache) -> logits [L, vocab]; appends to the KV cache."""
-        c, W = self.cfg, self.w
         ids = torch.as_tensor(np.asarray(ids, np.int64))
-        L = ids.shape[0]
-        h = W["model.embed_tokens.weight"][ids]
+        h = self.hidden(self.w["model.embed_tokens.weight"][ids])
+        head = self.w["model.embed_tokens.weight"] if self.cfg.tie_embeddings else self.w["lm_head.weight"]
+        return h @ head.t()
+
+    def hidden(self, h: torch.Tensor) -> torch.Tensor:
+        """Qwen2ModelInner.forward(embeddings:cache:) (Qwen2LM.swift:176-186): embeddings [L, hidden] -> final-norm hidden states."""
+        c, W = self.cfg, self.w
+        L = h.shape[0]
         for l in range(c.n_layers):
             p = f"model.layers.{l}"
             xn = _rms(h, W[p + ".input_layernorm.weight"], c.rms_eps)
@@ -102,9 +107,7 @@ class LMOracle:
             u = xn @ W[p + ".mlp.up_proj.weight"].t()
             h = h + (torch.nn.functional.silu(g) * u) @ W[p + ".mlp.down_proj.weight"].t()
         self.offset += L
-        h = _rms(h, W["model.norm.weight"], c.rms_eps)
-        head = W["model.embed_tokens.weight"] if c.tie_embeddings else W["lm_head.weight"]
-        return h @ head.t()
+        return _rms(h, W["model.norm.weight"], c.rms_eps)
 
 
 def top_p_filter(logits: np.ndarray, history, rep_penalty: float, temperature: float, top_p: float) -> np.ndarray:
@@ -177,3 +180,52 @@ def parse_output(tokens: list[int]) -> list[list[int]]:
         l3.append(f[b + 5] - 5 * 4096)
         l3.append(f[b + 6] - 6 * 4096)
     return [l1, l2, l3]
+
+
+# ---- CosyVoice2 Qwen2LM (TTS/CosyVoice2/LLM/Qwen2LM.swift:335-503) ---------------------------------------------------
+def _inv_cdf(p: np.ndarray, u: float) -> int:
+    c = np.cumsum(np.asarray(p, np.float64))
+    return int(min(np.searchsorted(c, u * c[-1], side="right"), len(p) - 1))
+
+
+def ras_sampling(logp: np.ndarray, decoded: list[int], draws, top_p=0.8, top_k=25, win=10, tau=0.1) -> int:
+    """rasSampling (:463-488) with nucleusSampling (:433-461); `draws` yields the explicit uniforms."""
+    x = np.asarray(logp, np.float64)
+    probs = np.exp(x - x.max()); probs /= probs.sum()
+    order = np.argsort(-probs, kind="stable")
+    sp = probs[order]
+    n = min(int((np.cumsum(sp) < top_p).sum()) + 1, top_k)
+    tok = int(order[_inv_cdf(sp[:n], next(draws))])
+    if decoded:
+        rep = sum(1 for t in decoded[-win:] if t == tok)
+        if rep >= win * tau:
+            tok = _inv_cdf(probs, next(draws))
+    return tok
+
+
+def qwen2lm_inference(model: "LMOracle", lm_input: np.ndarray, head_w, head_b, speech_emb, eos: int, min_len: int, max_len: int, uniforms) -> list[int]:
+    """inferenceLoop (:379-427): lm_input [n, hidden] embeddings; returns emitted speech tokens."""
+    draws = iter(list(uniforms) + [uniforms[-1]] * 100000)
+    hw, hb, se = torch.from_numpy(head_w), torch.from_numpy(head_b), torch.from_numpy(speech_emb)
+    model.reset()
+    out: list[int] = []
+    cur = torch.from_numpy(np.ascontiguousarray(lm_input, np.float32))
+    for i in range(max_len):
+        y = model.hidden(cur)
+        logits = y[-1] @ hw.t() + hb
+        logp = torch.log(torch.softmax(logits, dim=-1)).numpy()
+        trials = 0
+        while True:
+            top = ras_sampling(logp, out, draws)
+            if not (i < min_len and top == eos):
+                break
+            trials += 1
+            if trials > 100:
+                break
+        if top == eos:
+            break
+        cur = se[top][None, :]
+        if top > eos:
+            continue
+        out.append(top)
+    return out

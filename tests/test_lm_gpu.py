@@ -101,3 +101,27 @@ def test_parse_output_host_logic():
     frame = [off + 7, off + 4096 + 1, off + 2 * 4096 + 2, off + 3 * 4096 + 3, off + 4 * 4096 + 4, off + 5 * 4096 + 5, off + 6 * 4096 + 6]
     toks = [HL.AUDIO_CODE_DATA_START_MARKER] + frame * 2 + [HL.END_TOKEN]
     assert HL.parse_output(toks) == OL.parse_output(toks) == [[7, 7], [1, 4, 1, 4], [2, 3, 5, 6, 2, 3, 5, 6]]
+
+
+def test_qwen2lm_ras_inference_matches_oracle(ctx):
+    """CosyVoice2 Qwen2LM.inference: embedding-row prompt, speech-embedding feedback, llm_decoder head, RAS sampling with an
+    explicit uniform stream (EOS rejection below min_len consumes extra draws on both sides)."""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    cfg = S.LM_CONFIGS["qwen-micro"]
+    S_TOK = 200                                       # reduced speech vocabulary: EOS hits are likely -> exercises rejection + stop
+    w = S.lm_weights(cfg, seed=5, round_to="f16")
+    w.update(S.qwen2lm_extra_weights(cfg, S_TOK, seed=5, round_to="f16"))
+    model = HL.CausalLM.load(ctx, cfg, w, m.F16)
+    q = HL.Qwen2LM(model, w, speech_token_size=S_TOK)
+    ora = OL.LMOracle(cfg, {k: v for k, v in w.items() if k.startswith("model.")})
+    text, ptext, pspeech = [11, 12, 13, 14, 15, 16], [5, 6, 7], [3, 4, 5, 6]
+    u = np.random.default_rng(9).random(4000).astype(np.float32)
+    got = q.inference(text, ptext, pspeech, u)
+    x = q.lm_input(text, ptext, pspeech)
+    ref = OL.qwen2lm_inference(ora, x, w["llm_decoder.weight"], w["llm_decoder.bias"], w["speech_embedding.weight"], S_TOK,
+                               int(len(text) * 2.0), int(len(text) * 20.0), u)
+    assert all(0 <= t < S_TOK for t in got) and len(got) >= int(len(text) * 2.0) - 1
+    k = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
+    assert k >= 6, (got, ref)                         # streams may fork at an f16-moved CDF / top-k boundary, never early
+    model.close()
