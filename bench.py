@@ -125,6 +125,30 @@ def codec_bench(ctx, torch):
     res["dac_speech_decode"] = {"samples_per_s": round(d_out / (ms * 1e-3), 0), "ms": round(ms, 3), "samples": d_out,
                                 "realtime_factor": round(d_out / 24000.0 / (ms * 1e-3), 1)}
     dd.close()
+    # ---- HiFT (CosyVoice2 vocoder): 10 s of 50 Hz mel -> 240 000 samples, source noise included as an input
+    from mlx_swift_audio_amd import hift as HH
+    hcfg = S.HIFT_CONFIGS["hift_cosyvoice2"]
+    hg = HH.HiFTGenerator.load(ctx, hcfg, S.hift_weights(hcfg, 0))
+    T = 500
+    h_out = T * hg.up
+    mel = (torch.randn(hcfg.in_channels, T, device="cuda") * 1.5 - 2.0).contiguous()
+    hnoise = torch.randn(h_out, hcfg.nb_harmonics + 1, device="cuda")
+    hpcm = torch.empty(h_out, device="cuda")
+
+    def run_hift():
+        ctx.check(ctx.lib.mia_hift_vocode(hg.h, mel.data_ptr(), T, hnoise.data_ptr(), None, 0, hpcm.data_ptr(), None, 1))
+
+    for _ in range(2):
+        run_hift()
+    e0.record()
+    for _ in range(reps):
+        run_hift()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    res["hift_cosyvoice2_vocode"] = {"samples_per_s": round(h_out / (ms * 1e-3), 0), "ms": round(ms, 3), "samples": h_out,
+                                     "realtime_factor": round(h_out / 24000.0 / (ms * 1e-3), 1)}
+    hg.close()
     return res
 
 

@@ -277,6 +277,41 @@ void mia_s3tok_free(mia_s3tok* s3);
 int mia_s3tok_encode(mia_s3tok* s3, const float* mel, const int32_t* mel_len, int B, int T, int32_t* tokens, int tokens_stride,
                      int32_t* tok_len, int mem);
 
+/* ---- HiFT vocoder (80-bin mel @ 50 Hz -> 24 kHz waveform) ------------------------------------------ */
+/* Constructor arguments of CosyHiFTGenerator (TTS/CosyVoice2/HiFiGAN/CosyHiFTGenerator.swift:283-300).  n_fft 16 / hop 4 are
+ * fixed (istftParams).  The residual-block dilations are shared by every block ([1,3,5] in the reference). */
+typedef struct {
+  int32_t in_channels, base_channels, nb_harmonics, sampling_rate;
+  int32_t n_ups; int32_t up_rates[4]; int32_t up_kernels[4];
+  int32_t n_res_kernels; int32_t res_kernels[4];
+  int32_t src_res_kernels[4];          /* one per upsample stage */
+  int32_t n_dilations; int32_t dilations[4];
+  float nsf_alpha, nsf_sigma, voiced_threshold, lrelu_slope, audio_limit;
+} mia_hift_config;
+typedef struct mia_hift mia_hift;
+/* float32 tensors, Module key schema of the reference (CosyHiFTGenerator.swift:272-279): f0_predictor.condnet_{0,2,4,6,8}.*,
+ * f0_predictor.classifier.*, m_source.l_linear.*, conv_pre.*, ups.N.*, source_downs.N.*, source_resblocks.N.{convs1,convs2}.M.*,
+ * source_resblocks.N.{activations1,activations2}.M.alpha, resblocks.N.(same), conv_post.*  (Conv1d weight [Cout][K][Cin],
+ * ConvTransposed1d weight [Cout][K][Cin]). */
+mia_hift* mia_hift_load(mia_ctx* ctx, const mia_hift_config* cfg, const mia_tensor_view* tensors, int n_tensors);
+void mia_hift_free(mia_hift* h);
+/* samples produced per mel frame: prod(up_rates) * hop (480) */
+int mia_hift_upsample_factor(const mia_hift* h);
+/* CosyF0Predictor (CosyHiFTGenerator.swift:236-255): mel float32 [in_channels][T] (channel-major as in the reference) -> f0 [T]. */
+int mia_hift_f0(mia_hift* h, const float* mel, int T, float* f0, int mem);
+/* f0Upsample + SourceModuleHnNSF2 / SineGen2 (CosyHiFTGenerator.swift:96-153,190-203,408-410,487-495): f0 [T] -> source [480 T].
+ * noise: the reference's MLXRandom.normal draw, float32 [480 T][nb_harmonics+1], or NULL for no additive noise.  The reference's
+ * random initial phase (:103-111) only touches sample 0 of the full-rate `rad` track, which the 480:1 linear downsample never
+ * reads (it reads samples 480 i + 239 / + 240), so it has no effect on the output and is not an input here.  T <= 17000. */
+int mia_hift_source(mia_hift* h, const float* f0, int T, const float* noise, float* source, int mem);
+/* CosyHiFTGenerator.decode(x:s:) (:412-475): mel [in_channels][T] + source [480 T] -> waveform [480 T], clipped to +-audio_limit. */
+int mia_hift_decode(mia_hift* h, const float* mel, int T, const float* source, float* pcm, int mem);
+/* CosyHiFTGenerator.callAsFunction (:482-505): f0 -> source (its first cache_len samples replaced by cache_source, the
+ * streaming hand-over) -> decode.  source_out (nullable) receives the source actually used.  Every buffer lives in `mem`;
+ * with MIA_MEM_DEVICE nothing is copied and the call returns after enqueueing on the ctx stream. */
+int mia_hift_vocode(mia_hift* h, const float* mel, int T, const float* noise, const float* cache_source, int cache_len,
+                    float* pcm, float* source_out, int mem);
+
 #ifdef __cplusplus
 }
 #endif

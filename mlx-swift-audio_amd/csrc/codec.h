@@ -12,14 +12,18 @@ struct ConvGemmArgs {
   const float* W = nullptr; int64_t w_phase_stride = 0;
   const float* bias = nullptr;
   const float* alpha = nullptr;        // snake prologue on X (per input channel), or null
+  const float* ralpha = nullptr;       // snake multiplier (per channel); null -> 1/(alpha + 1e-9) (SNAC / DAC form)
+  float lrelu_slope = 0.f;             // > 0: leaky-ReLU prologue on X instead of snake
   float* Y = nullptr; int64_t ldy = 0; int T_out = 0;
   int y_row_mul = 1, y_row_off = 0, y_phase_step = 0;
   const float* R = nullptr; int64_t ldr = 0;   // residual (same row mapping as Y)
   const float* noise = nullptr;        // if set: Y = R + noise[row] * (acc + bias)
+  float out_scale = 0.f;               // != 0: Y = out_scale * (act(acc + bias) + R) + R2
+  const float* R2 = nullptr;           // second residual, added after the scale (row stride ldr)
   int M = 0, N = 0, Cin = 0, taps = 1, dil = 1, pad = 0;
   int tanh_out = 0;
   int x_row_mul = 1;                   // convolution stride: A(m, tap, c) = X[m*x_row_mul + tap*dil - pad][c]
-  int gelu = 0;                        // exact-erf GELU on acc + bias (before the residual)
+  int gelu = 0;                        // activation on acc + bias (before the residual): 1 = exact-erf GELU, 2 = ELU, 3 = abs
   int64_t ldw = 0;                     // row stride of W (0 = taps*Cin, i.e. dense)
 };
 

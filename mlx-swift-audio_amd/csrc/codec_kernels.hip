@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
     float al[4] = {0.f, 0.f, 0.f, 0.f}, ral[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.alpha) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { al[j] = g.alpha[c0 + j]; ral[j] = 1.0f / (al[j] + 1e-9f); }
+      for (int j = 0; j < 4; ++j) { al[j] = g.alpha[c0 + j]; ral[j] = g.ralpha ? g.ralpha[c0 + j] : 1.0f / (al[j] + 1e-9f); }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -64,6 +64,9 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
         if (g.alpha) {
           v.x = snake_p(v.x, al[0], ral[0]); v.y = snake_p(v.y, al[1], ral[1]);
           v.z = snake_p(v.z, al[2], ral[2]); v.w = snake_p(v.w, al[3], ral[3]);
+        } else if (g.lrelu_slope > 0.f) {
+          v.x = v.x > 0.f ? v.x : v.x * g.lrelu_slope; v.y = v.y > 0.f ? v.y : v.y * g.lrelu_slope;
+          v.z = v.z > 0.f ? v.z : v.z * g.lrelu_slope; v.w = v.w > 0.f ? v.w : v.w * g.lrelu_slope;
         }
       }
       ra[i] = v;
@@ -132,9 +135,13 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
         const int64_t yr = (int64_t)m * g.y_row_mul + g.y_row_off + (int64_t)z * g.y_phase_step;
         if (yr < 0 || yr >= g.T_out) continue;
         float v = acc[i][j][r] + bias;
-        if (g.gelu) v = gelu_erf(v);
+        if (g.gelu == 1) v = gelu_erf(v);
+        else if (g.gelu == 2) v = v > 0.f ? v : expm1f(v);
+        else if (g.gelu == 3) v = fabsf(v);
         if (g.noise) v = g.R[yr * g.ldr + n] + g.noise[yr] * v;
         else if (g.R) v += g.R[yr * g.ldr + n];
+        if (g.out_scale != 0.f) v *= g.out_scale;
+        if (g.R2) v += g.R2[yr * g.ldr + n];
         if (g.tanh_out) v = tanhf(v);
         g.Y[yr * g.ldy + n] = v;
       }

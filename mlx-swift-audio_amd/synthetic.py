@@ -394,3 +394,72 @@ def qwen2lm_extra_weights(cfg: LMConfig, speech_token_size: int = 6561, seed: in
     w["llm_decoder.weight"] = round_array(rng.standard_normal((speech_token_size + 3, h), dtype=np.float32) * np.float32(1.0 / math.sqrt(h) * 4.0), round_to)
     w["llm_decoder.bias"] = (0.1 * rng.standard_normal(speech_token_size + 3)).astype(np.float32)
     return w
+
+
+# ---- HiFT vocoder (CosyHiFTGenerator.swift:283-300 defaults) ---------------------------------------------------------------
+@dataclass(frozen=True)
+class HiFTConfig:
+    in_channels: int = 80
+    base_channels: int = 512
+    nb_harmonics: int = 8
+    sampling_rate: int = 24000
+    up_rates: tuple = (8, 5, 3)
+    up_kernels: tuple = (16, 11, 7)
+    res_kernels: tuple = (3, 7, 11)
+    dilations: tuple = (1, 3, 5)
+    src_res_kernels: tuple = (7, 7, 11)
+    nsf_alpha: float = 0.1
+    nsf_sigma: float = 0.003
+    voiced_threshold: float = 10.0
+    lrelu_slope: float = 0.1
+    audio_limit: float = 0.99
+    n_fft: int = 16
+    hop: int = 4
+
+    @property
+    def upsample_factor(self) -> int:
+        return int(np.prod(self.up_rates)) * self.hop
+
+
+HIFT_CONFIGS = {"hift_cosyvoice2": HiFTConfig(), "hift_micro": HiFTConfig(base_channels=256)}
+
+
+def hift_weights(cfg: HiFTConfig, seed: int = 0) -> dict[str, np.ndarray]:
+    """Random-init CosyHiFTGenerator tensors with the reference's Module key paths (CosyHiFTGenerator.swift:272-279).  Scales are
+    chosen so that the synthetic F0 spans voiced and unvoiced frames and the spectrum head stays inside exp()'s useful range."""
+    w: dict[str, np.ndarray] = {}
+    B, H = cfg.base_channels, cfg.nb_harmonics + 1
+
+    def t(name, shape, std):
+        rng = np.random.Generator(np.random.PCG64(_key_seed(name, seed)))
+        w[name] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+    def conv(p, co, k, ci, gain=1.0):
+        t(p + ".weight", (co, k, ci), gain / math.sqrt(k * ci)); t(p + ".bias", (co,), 0.05)
+
+    def resblock(p, c, k):
+        for i in range(len(cfg.dilations)):
+            conv(f"{p}.convs1.{i}", c, k, c); conv(f"{p}.convs2.{i}", c, k, c, 0.4)
+            for a in ("activations1", "activations2"):
+                rng = np.random.Generator(np.random.PCG64(_key_seed(f"{p}.{a}.{i}.alpha", seed)))
+                al = (1.0 + 0.5 * rng.standard_normal(c)).astype(np.float32)
+                al[0] = 0.0; al[1] = 1e-6; al[2] = -1e-6          # exercise the clamp branches of Snake (HiFiGAN.swift:53-66)
+                w[f"{p}.{a}.{i}.alpha"] = al
+
+    for j, i in enumerate((0, 2, 4, 6, 8)):
+        conv(f"f0_predictor.condnet_{i}", B, 3, cfg.in_channels if j == 0 else B, 1.3)
+    t("f0_predictor.classifier.weight", (1, B), 70.0 / math.sqrt(B)); t("f0_predictor.classifier.bias", (1,), 1.0)
+    t("m_source.l_linear.weight", (1, H), 1.0); t("m_source.l_linear.bias", (1,), 0.05)
+    conv("conv_pre", B, 7, cfg.in_channels)
+    n = len(cfg.up_rates)
+    for i in range(n):
+        ci, co = B >> i, B >> (i + 1)
+        k, u = cfg.up_kernels[i], cfg.up_rates[i]
+        t(f"ups.{i}.weight", (co, k, ci), 1.0 / math.sqrt(ci * k / u)); t(f"ups.{i}.bias", (co,), 0.05)
+        dr = int(np.prod(cfg.up_rates[i + 1:])) if i + 1 < n else 1
+        conv(f"source_downs.{i}", co, 1 if dr == 1 else 2 * dr, cfg.n_fft + 2, 0.5)
+        resblock(f"source_resblocks.{i}", co, cfg.src_res_kernels[i])
+        for k2, kk in enumerate(cfg.res_kernels):
+            resblock(f"resblocks.{i * len(cfg.res_kernels) + k2}", co, kk)
+    conv("conv_post", cfg.n_fft + 2, 7, B >> n, 0.25)
+    return w
