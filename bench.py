@@ -149,6 +149,36 @@ def codec_bench(ctx, torch):
     res["hift_cosyvoice2_vocode"] = {"samples_per_s": round(h_out / (ms * 1e-3), 0), "ms": round(ms, 3), "samples": h_out,
                                      "realtime_factor": round(h_out / 24000.0 / (ms * 1e-3), 1)}
     hg.close()
+    # ---- CosyVoice2 flow: 375 new + 150 prompt speech tokens (15 s + 6 s) -> 750 new mel frames, 10 Euler steps with CFG
+    from mlx_swift_audio_amd import flow as HFL
+    fcfg = S.FLOW_CONFIGS["flow_cosyvoice2"]
+    fm = HFL.FlowModule.load(ctx, fcfg, S.flow_weights(fcfg, 0))
+    n_tok, n_prompt = 375, 150
+    Tm = 2 * (n_tok + n_prompt)
+    tok = torch.from_numpy(rng.integers(0, fcfg.vocab_size, n_tok).astype(np.int32)).cuda()
+    ptok = torch.from_numpy(rng.integers(0, fcfg.vocab_size, n_prompt).astype(np.int32)).cuda()
+    pfeat = torch.randn(2 * n_prompt, 80, device="cuda")
+    spk = torch.randn(fcfg.spk_embed_dim, device="cuda")
+    zz = torch.randn(80, Tm, device="cuda")
+    fmel = torch.empty(80, Tm - 2 * n_prompt, device="cuda")
+
+    def run_flow():
+        ctx.check(ctx.lib.mia_flow_inference(fm.h, tok.data_ptr(), n_tok, ptok.data_ptr(), n_prompt, pfeat.data_ptr(), 2 * n_prompt,
+                                             spk.data_ptr(), zz.data_ptr(), 0, fmel.data_ptr(), 1))
+
+    run_flow()
+    e0.record()
+    freps = 3
+    for _ in range(freps):
+        run_flow()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / freps
+    n_new = Tm - 2 * n_prompt
+    res["flow_cosyvoice2_inference"] = {"mel_frames_per_s": round(n_new / (ms * 1e-3), 0), "ms": round(ms, 3), "new_mel_frames": n_new,
+                                        "total_frames": Tm, "euler_steps": fcfg.n_timesteps,
+                                        "realtime_factor": round(n_new / 50.0 / (ms * 1e-3), 1)}
+    fm.close()
     return res
 
 

@@ -312,6 +312,36 @@ int mia_hift_decode(mia_hift* h, const float* mel, int T, const float* source, f
 int mia_hift_vocode(mia_hift* h, const float* mel, int T, const float* noise, const float* cache_source, int cache_len,
                     float* pcm, float* source_out, int mem);
 
+/* ---- CosyVoice2 flow (speech tokens -> 80-bin mel @ 50 Hz) ---------------------------------------- */
+/* FlowConfig (TTS/CosyVoice2/Config/CosyVoice2Config.swift:79-127).  Built for the shapes the reference engine uses: head dim 64 in
+ * both the conformer encoder (input_size = 64 * enc_heads) and the estimator, mel 80, dec_in_channels = 4 * 80, one U-Net level. */
+typedef struct {
+  int32_t input_size, output_size, spk_embed_dim, vocab_size, pre_lookahead_len, n_timesteps;
+  int32_t enc_heads, enc_linear_units, enc_blocks, enc_up_blocks, upsample_stride;
+  int32_t dec_in_channels, dec_channels, dec_heads, dec_n_blocks, dec_mid_blocks;
+  float cfg_rate;   /* inference_cfg_rate, 0.7 */
+} mia_flow_config;
+typedef struct mia_flow mia_flow;
+/* float32 tensors under the reference's (remapped) Module keys (CosyVoice2TTS.swift:320-336): input_embedding.weight,
+ * spk_embed_affine_layer.*, encoder.{embed,up_embed}.{linear,norm}.*, encoder.pre_lookahead_layer.conv{1,2}.*, encoder.up_layer.conv.*,
+ * encoder.{encoders,up_encoders}.N.{self_attn.{linear_q,linear_k,linear_v,linear_out,linear_pos}.*, self_attn.pos_bias_{u,v},
+ * feed_forward.{w_1,w_2}.*, norm_mha.*, norm_ff.*}, encoder.after_norm.*, encoder_proj.*, decoder.estimator.time_mlp.linear_{1,2}.*,
+ * decoder.estimator.{down_blocks.0,mid_blocks.N,up_blocks.0}.{resnet.{mlp_linear,block{1,2}.conv.conv,block{1,2}.norm,res_conv}.*,
+ * transformers.K.{norm1,norm3,attn.{query_proj,key_proj,value_proj,out_proj},ff.layers.{0,1}}.*}, ...down_blocks.0.downsample.conv.*,
+ * ...up_blocks.0.upsample.conv.*, decoder.estimator.final_block.{conv.conv,norm}.*, decoder.estimator.final_proj.*. */
+mia_flow* mia_flow_load(mia_ctx* ctx, const mia_flow_config* cfg, const mia_tensor_view* tensors, int n_tensors);
+void mia_flow_free(mia_flow* f);
+/* input_embedding -> UpsampleConformerEncoder(streaming: false) -> encoder_proj (CosyVoice2Model.swift:496-522,
+ * UpsampleConformerEncoder.swift:407-474): token int32 [n] -> mu float32 [upsample_stride * n][80]. */
+int mia_flow_encode(mia_flow* f, const int32_t* token, int n_token, float* mu, int mem);
+/* CosyVoice2FlowModule.inference(finalize: true) (CosyVoice2Model.swift:467-553) for one utterance:
+ *   token [n_token], prompt_token [n_prompt] int32; prompt_feat float32 [prompt_feat_len][80] (the prompt's mel, time-major as in the
+ *   reference); embedding float32 [spk_embed_dim]; z float32 [80][T], T = upsample_stride (n_token + n_prompt): the CFM's initial
+ *   noise, which the reference draws internally (CosyVoice2CFM.swift:86) -- explicit here; n_timesteps <= 0 means cfg.n_timesteps.
+ *   mel out float32 [80][T - prompt_feat_len] (channel-major, what CosyHiFTGenerator consumes).  Every buffer lives in `mem`. */
+int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
+                       int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, float* mel, int mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,8 +23,10 @@ struct ConvGemmArgs {
   int M = 0, N = 0, Cin = 0, taps = 1, dil = 1, pad = 0;
   int tanh_out = 0;
   int x_row_mul = 1;                   // convolution stride: A(m, tap, c) = X[m*x_row_mul + tap*dil - pad][c]
-  int gelu = 0;                        // activation on acc + bias (before the residual): 1 = exact-erf GELU, 2 = ELU, 3 = abs
+  int gelu = 0;                        // activation on acc + bias (before the residual): 1 = exact-erf GELU, 2 = ELU, 3 = abs, 4 = SiLU, 5 = leaky-ReLU(0.01)
   int64_t ldw = 0;                     // row stride of W (0 = taps*Cin, i.e. dense)
+  int x_row_div = 1;                   // nearest-neighbour upsampled input: A(m, tap, c) = X[(m*x_row_mul + tap*dil - pad) div x_row_div][c]
+  int seg = 0;                         // > 0: rows are stacked sequences of `seg` rows; taps never cross a sequence boundary
 };
 
 constexpr int MIA_MAX_LEVELS = 4;

@@ -57,9 +57,12 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + s_row + 32 * i;
-      const int64_t xr = (int64_t)m * g.x_row_mul + (int64_t)tap * g.dil - g.pad;
+      int64_t xr = (int64_t)m * g.x_row_mul + (int64_t)tap * g.dil - g.pad;
+      bool ok = m < g.M && xr >= 0;
+      if (g.seg > 0) { const int64_t s0 = (int64_t)(m / g.seg) * g.seg; ok = ok && xr >= s0 && xr < s0 + g.seg; }
+      if (g.x_row_div > 1) xr /= g.x_row_div;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < g.M && xr >= 0 && xr < g.T_in) {
+      if (ok && xr < g.T_in) {
         v = *reinterpret_cast<const float4*>(g.X + xr * g.ldx + c0);
         if (g.alpha) {
           v.x = snake_p(v.x, al[0], ral[0]); v.y = snake_p(v.y, al[1], ral[1]);
@@ -138,6 +141,8 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
         if (g.gelu == 1) v = gelu_erf(v);
         else if (g.gelu == 2) v = v > 0.f ? v : expm1f(v);
         else if (g.gelu == 3) v = fabsf(v);
+        else if (g.gelu == 4) v = v / (1.0f + expf(-v));
+        else if (g.gelu == 5) v = v > 0.f ? v : 0.01f * v;
         if (g.noise) v = g.R[yr * g.ldr + n] + g.noise[yr] * v;
         else if (g.R) v += g.R[yr * g.ldr + n];
         if (g.out_scale != 0.f) v *= g.out_scale;

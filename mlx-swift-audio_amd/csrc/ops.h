@@ -14,3 +14,17 @@ int mia_norm_launch(const float* x, int64_t ldx, const float* gamma, const float
 const char* mia_enc_attention_check(int B, int T, int H, int Tpad, int64_t ld_qk, int64_t ld_out);
 int mia_enc_attention_launch(const void* qk, int64_t ld_qk, const void* vt, void* out, int64_t ld_out, int B, int T, int H,
                              int Tpad, int dtype, hipStream_t s);
+
+// ---- attn_f32.hip (fp32 flash attention, d_h = 64; optional positional keys) ----------------------
+struct AttnF32Args {
+  const float* q = nullptr; int64_t ldq = 0;    // [B*T][ldq], head h in columns h*64 .. h*64+63
+  const float* k = nullptr; int64_t ldk = 0;
+  const float* v = nullptr; int64_t ldv = 0;
+  const float* p = nullptr; int64_t ldp = 0;    // optional positional keys [T][ldp] shared by the batch (+ bias_u / bias_v [H][64])
+  const float* bias_u = nullptr; const float* bias_v = nullptr;
+  float* out = nullptr; int64_t ldo = 0;
+  int B = 1, T = 0, H = 0;
+  float scale = 0.125f;
+};
+const char* mia_attn_f32_check(const AttnF32Args& a);
+int mia_attn_f32_launch(const AttnF32Args& a, hipStream_t s);

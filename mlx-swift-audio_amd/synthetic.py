@@ -463,3 +463,104 @@ def hift_weights(cfg: HiFTConfig, seed: int = 0) -> dict[str, np.ndarray]:
             resblock(f"resblocks.{i * len(cfg.res_kernels) + k2}", co, kk)
     conv("conv_post", cfg.n_fft + 2, 7, B >> n, 0.25)
     return w
+
+
+# ---- CosyVoice2 flow (FlowConfig, TTS/CosyVoice2/Config/CosyVoice2Config.swift:79-127) -----------------------------------------
+@dataclass(frozen=True)
+class FlowConfig:
+    input_size: int = 512
+    output_size: int = 80
+    spk_embed_dim: int = 192
+    vocab_size: int = 6561
+    token_mel_ratio: int = 2
+    pre_lookahead_len: int = 3
+    n_timesteps: int = 10
+    enc_heads: int = 8
+    enc_linear_units: int = 2048
+    enc_blocks: int = 6
+    enc_up_blocks: int = 4
+    upsample_stride: int = 2
+    dec_in_channels: int = 320
+    dec_channels: int = 256
+    dec_heads: int = 8
+    dec_n_blocks: int = 4
+    dec_mid_blocks: int = 12
+    cfg_rate: float = 0.7
+
+
+FLOW_CONFIGS = {"flow_cosyvoice2": FlowConfig(),
+                "flow_micro": FlowConfig(input_size=128, vocab_size=97, enc_heads=2, enc_linear_units=256, enc_blocks=2, enc_up_blocks=1,
+                                         dec_channels=64, dec_heads=2, dec_n_blocks=1, dec_mid_blocks=2)}
+
+
+def flow_weights(cfg: FlowConfig, seed: int = 0) -> dict[str, np.ndarray]:
+    """Random-init CosyVoice2FlowModule tensors with the reference's (remapped) Module key paths (CosyVoice2TTS.swift:320-336)."""
+    w: dict[str, np.ndarray] = {}
+    D, M = cfg.input_size, cfg.output_size
+
+    def t(name, shape, std):
+        rng = np.random.Generator(np.random.PCG64(_key_seed(name, seed)))
+        w[name] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+    def lin(p, o, i, bias=True, gain=1.0):
+        t(p + ".weight", (o, i), gain / math.sqrt(i))
+        if bias:
+            t(p + ".bias", (o,), 0.05)
+
+    def conv(p, o, k, i, gain=1.0):
+        t(p + ".weight", (o, k, i), gain / math.sqrt(k * i)); t(p + ".bias", (o,), 0.05)
+
+    def ln(p, d):
+        t(p + ".weight", (d,), 0.1); w[p + ".weight"] += 1.0
+        t(p + ".bias", (d,), 0.1)
+
+    t("input_embedding.weight", (cfg.vocab_size, D), 1.0)
+    lin("spk_embed_affine_layer", M, cfg.spk_embed_dim)
+    e = "encoder"
+    for p in (e + ".embed", e + ".up_embed"):
+        lin(p + ".linear", D, D); ln(p + ".norm", D)
+    conv(e + ".pre_lookahead_layer.conv1", D, cfg.pre_lookahead_len + 1, D)
+    conv(e + ".pre_lookahead_layer.conv2", D, 3, D)
+    conv(e + ".up_layer.conv", D, 2 * cfg.upsample_stride + 1, D)
+    dk = D // cfg.enc_heads
+    for grp, n in ((".encoders", cfg.enc_blocks), (".up_encoders", cfg.enc_up_blocks)):
+        for i in range(n):
+            p = f"{e}{grp}.{i}"
+            for nm in ("linear_q", "linear_k", "linear_v", "linear_out"):
+                lin(f"{p}.self_attn.{nm}", D, D, gain=0.7 if nm != "linear_out" else 0.5)
+            lin(f"{p}.self_attn.linear_pos", D, D, bias=False)
+            t(f"{p}.self_attn.pos_bias_u", (cfg.enc_heads, dk), 0.3); t(f"{p}.self_attn.pos_bias_v", (cfg.enc_heads, dk), 0.3)
+            lin(f"{p}.feed_forward.w_1", cfg.enc_linear_units, D); lin(f"{p}.feed_forward.w_2", D, cfg.enc_linear_units, gain=0.5)
+            ln(p + ".norm_ff", D); ln(p + ".norm_mha", D)
+    ln(e + ".after_norm", D)
+    lin("encoder_proj", M, D)
+    d = "decoder.estimator"
+    C, TE = cfg.dec_channels, 4 * cfg.dec_channels
+    inner = cfg.dec_heads * 64
+    lin(d + ".time_mlp.linear_1", TE, cfg.dec_in_channels); lin(d + ".time_mlp.linear_2", TE, TE)
+
+    def resnet(p, ci, co):
+        lin(p + ".mlp_linear", co, TE)
+        conv(p + ".block1.conv.conv", co, 3, ci); ln(p + ".block1.norm", co)
+        conv(p + ".block2.conv.conv", co, 3, co); ln(p + ".block2.norm", co)
+        conv(p + ".res_conv", co, 1, ci)
+
+    def tblock(p):
+        ln(p + ".norm1", C); ln(p + ".norm3", C)
+        for nm in ("query_proj", "key_proj", "value_proj"):
+            lin(f"{p}.attn.{nm}", inner, C, bias=False)
+        lin(p + ".attn.out_proj", C, inner, gain=0.5)
+        lin(p + ".ff.layers.0", 4 * C, C); lin(p + ".ff.layers.1", C, 4 * C, gain=0.5)
+
+    def block(p, ci):
+        resnet(p + ".resnet", ci, C)
+        for j in range(cfg.dec_n_blocks):
+            tblock(f"{p}.transformers.{j}")
+
+    block(d + ".down_blocks.0", cfg.dec_in_channels); conv(d + ".down_blocks.0.downsample.conv", C, 3, C)
+    for i in range(cfg.dec_mid_blocks):
+        block(f"{d}.mid_blocks.{i}", C)
+    block(d + ".up_blocks.0", 2 * C); conv(d + ".up_blocks.0.upsample.conv", C, 3, C)
+    conv(d + ".final_block.conv.conv", C, 3, C); ln(d + ".final_block.norm", C)
+    conv(d + ".final_proj", M, 1, C)
+    return w
