@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
   const int z = blockIdx.z;
   const float* __restrict__ W = g.W + (int64_t)z * g.w_phase_stride;
+  const float* __restrict__ X = g.X + (int64_t)z * g.x_phase_step * g.ldx;   // stacked sequences: phase z reads its own rows only
   const int Ktot = g.taps * g.Cin;
   const int64_t ldw = g.ldw > 0 ? g.ldw : Ktot;
 
@@ -57,13 +58,10 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + s_row + 32 * i;
-      int64_t xr = (int64_t)m * g.x_row_mul + (int64_t)tap * g.dil - g.pad;
-      bool ok = m < g.M && xr >= 0;
-      if (g.seg > 0) { const int64_t s0 = (int64_t)(m / g.seg) * g.seg; ok = ok && xr >= s0 && xr < s0 + g.seg; }
-      if (g.x_row_div > 1) xr /= g.x_row_div;
+      const int xr = m * g.x_row_mul + tap * g.dil - g.pad;    // host checks that M * x_row_mul fits 31 bits
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok && xr < g.T_in) {
-        v = *reinterpret_cast<const float4*>(g.X + xr * g.ldx + c0);
+      if (m < g.M && xr >= 0 && xr < g.T_in) {
+        v = *reinterpret_cast<const float4*>(X + (int64_t)xr * g.ldx + c0);
         if (g.alpha) {
           v.x = snake_p(v.x, al[0], ral[0]); v.y = snake_p(v.y, al[1], ral[1]);
           v.z = snake_p(v.z, al[2], ral[2]); v.w = snake_p(v.w, al[3], ral[3]);
@@ -139,9 +137,9 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
         if (yr < 0 || yr >= g.T_out) continue;
         float v = acc[i][j][r] + bias;
         if (g.gelu == 1) v = gelu_erf(v);
-        else if (g.gelu == 2) v = v > 0.f ? v : expm1f(v);
+        else if (g.gelu == 2) v = v > 0.f ? v : (__expf(v) - 1.0f);
         else if (g.gelu == 3) v = fabsf(v);
-        else if (g.gelu == 4) v = v / (1.0f + expf(-v));
+        else if (g.gelu == 4) v = v / (1.0f + __expf(-v));
         else if (g.gelu == 5) v = v > 0.f ? v : 0.01f * v;
         if (g.noise) v = g.R[yr * g.ldr + n] + g.noise[yr] * v;
         else if (g.R) v += g.R[yr * g.ldr + n];
@@ -257,6 +255,7 @@ const char* codec_conv_gemm_check(const ConvGemmArgs& g) {
   if (g.Cin % GBK) return "conv_gemm: Cin must be a multiple of 32";
   if (g.ldx % 4 || ((uintptr_t)g.X & 15) || ((uintptr_t)g.W & 15)) return "conv_gemm: X rows / W must be 16-byte aligned";
   if (g.noise && !g.R) return "conv_gemm: noise modulation needs the residual input";
+  if ((int64_t)g.M * g.x_row_mul + (int64_t)g.taps * g.dil > 0x7fffffffLL) return "conv_gemm: row index exceeds 31 bits";
   return nullptr;
 }
 

@@ -41,6 +41,15 @@ __global__ __launch_bounds__(256) void flow_gather(const int32_t* __restrict__ i
   *reinterpret_cast<float4*>(out + (int64_t)r * D + c) = *reinterpret_cast<const float4*>(table + (int64_t)id * D + c);
 }
 
+// nearest-neighbour upsampling: out[t] = x[t / stride]   (Upsample1D, UpsampleConformerEncoder.swift:41)
+__global__ __launch_bounds__(256) void flow_repeat_rows(const float* __restrict__ x, float* __restrict__ out, int T_out, int D, int stride) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int d4 = D >> 2;
+  if (e >= (int64_t)T_out * d4) return;
+  const int t = (int)(e / d4), c = (int)(e % d4) * 4;
+  *reinterpret_cast<float4*>(out + (int64_t)t * D + c) = *reinterpret_cast<const float4*>(x + (int64_t)(t / stride) * D + c);
+}
+
 // PositionalEncoding.createPE (Embedding.swift:33-52): pe[t][2 i] = sin(t w_i), pe[t][2 i + 1] = cos(t w_i), w_i = exp(2 i * (-ln 1e4 / D))
 __global__ __launch_bounds__(256) void flow_sinusoid(float* __restrict__ pe, int T, int D, float neg_log_over_d) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -261,15 +270,17 @@ struct Run {
   mia_flow* f; hipStream_t s; int rc = MIA_OK;
   bool fail(int code, const char* msg) { if (rc == MIA_OK) rc = mia_fail(f->ctx, code, "flow: %s", msg); return false; }
 
-  // Y[M][N] = act(X[M][K*taps] W^T + b) (+ R); taps > 1: causal / lookahead window starting `pad` rows back; seg = stacked sequences
+  // Y[M][N] = act(X[M][K*taps] W^T + b) (+ R); taps > 1: window starting `pad` rows back (zero outside the sequence); nseq > 1: X / Y / R
+  // are nseq stacked sequences of M rows each, convolved independently (one grid.z phase per sequence)
   bool gemm(const Lin& l, const float* X, int64_t ldx, int M, float* Y, int64_t ldy, int act = 0, const float* R = nullptr, int pad = 0,
-            int seg = 0, int T_in = 0, int x_row_div = 1) {
+            int nseq = 1) {
     if (rc != MIA_OK) return false;
     ConvGemmArgs g;
-    g.X = X; g.ldx = ldx; g.T_in = T_in ? T_in : M; g.W = l.w; g.bias = l.b; g.Y = Y; g.ldy = ldy; g.T_out = M; g.R = R; g.ldr = ldy;
-    g.M = M; g.N = l.N; g.Cin = l.K; g.taps = l.taps; g.pad = pad; g.gelu = act; g.seg = seg; g.x_row_div = x_row_div;
+    g.X = X; g.ldx = ldx; g.T_in = M; g.W = l.w; g.bias = l.b; g.Y = Y; g.ldy = ldy; g.T_out = M * nseq; g.R = R; g.ldr = ldy;
+    g.M = M; g.N = l.N; g.Cin = l.K; g.taps = l.taps; g.pad = pad; g.gelu = act;
+    if (nseq > 1) { g.x_phase_step = M; g.y_phase_step = M; }
     if (const char* e = codec_conv_gemm_check(g)) return fail(MIA_ERR_INVALID_ARGUMENT, e);
-    if (codec_conv_gemm_launch(g, 1, s)) return fail(MIA_ERR_DEVICE, "gemm launch failed");
+    if (codec_conv_gemm_launch(g, nseq, s)) return fail(MIA_ERR_DEVICE, "gemm launch failed");
     return true;
   }
   bool ln(const Norm& n, const float* x, float* y, int M, int D, float eps) {
@@ -349,7 +360,8 @@ int run_encoder(mia_flow* f, Bufs& b, const int32_t* d_ids, int Tt) {
   r.gemm(f->pl2, b.h, D, Tt, b.x, D, 0, b.x0, 2);
   for (const ConfLayer& l : f->enc) conformer_layer(r, l, b, Tt, D, H, FF);
   // Upsample1D: nearest repeat x stride, left pad 2 stride, conv k = 2 stride + 1
-  r.gemm(f->up_conv, b.x, D, T, b.h, D, 0, nullptr, 2 * st, 0, Tt, st);
+  hipLaunchKernelGGL(flow_repeat_rows, dim3((unsigned)(((int64_t)T * (D / 4) + 255) / 256)), dim3(256), 0, s, b.x, b.att, T, D, st);
+  r.gemm(f->up_conv, b.att, D, T, b.h, D, 0, nullptr, 2 * st);
   r.gemm(f->up_embed, b.h, D, T, b.x0, D);
   r.ln(f->up_embed_n, b.x0, b.x, T, D, 1e-5f);
   for (const ConfLayer& l : f->up_enc) conformer_layer(r, l, b, T, D, H, FF);
@@ -362,9 +374,9 @@ int run_encoder(mia_flow* f, Bufs& b, const int32_t* d_ids, int Tt) {
 // CausalResnetBlock1D (S3GenDecoder.swift:89-101) on the stacked pair X [2 T][Cin] -> Y [2 T][C]  (Y must not alias X)
 void resnet(Run& r, const Resnet& rn, Bufs& b, const float* X, int Cin, int T, int C, const float* tvec, float* Y) {
   const int M = 2 * T;
-  r.gemm(rn.c1, X, Cin, M, b.c1, C, 0, nullptr, 2, T);
+  r.gemm(rn.c1, X, Cin, T, b.c1, C, 0, nullptr, 2, 2);
   r.ln_mish(rn.n1, b.c1, tvec + (size_t)rn.idx * C, b.h1, M, C);
-  r.gemm(rn.c2, b.h1, C, M, b.c1, C, 0, nullptr, 2, T);
+  r.gemm(rn.c2, b.h1, C, T, b.c1, C, 0, nullptr, 2, 2);
   r.ln_mish(rn.n2, b.c1, nullptr, b.h1, M, C);
   r.gemm(rn.res, X, Cin, M, Y, C, 0, b.h1);
 }
@@ -554,7 +566,7 @@ int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int
     // skip -> right half of the up block's input; causal "downsample" conv (stride 1 for the single-level U-Net)
     MIA_HIP(ctx, hipMemcpy2DAsync(b.cat + C, (size_t)2 * C * 4, b.xr, (size_t)C * 4, (size_t)C * 4, M2, hipMemcpyDeviceToDevice, s));
     float* cur = b.xr2; float* nxt = b.xr;
-    r.gemm(f->down_conv, b.xr, C, M2, cur, C, 0, nullptr, 2, T);
+    r.gemm(f->down_conv, b.xr, C, T, cur, C, 0, nullptr, 2, 2);
     for (const UBlock& mb : f->mid) {
       resnet(r, mb.rn, b, cur, C, T, C, tvec, nxt);
       for (const TBlock& t : mb.tb) tblock(r, t, b, nxt, T, C, H);
@@ -563,9 +575,9 @@ int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int
     MIA_HIP(ctx, hipMemcpy2DAsync(b.cat, (size_t)2 * C * 4, cur, (size_t)C * 4, (size_t)C * 4, M2, hipMemcpyDeviceToDevice, s));
     resnet(r, f->up.rn, b, b.cat, 2 * C, T, C, tvec, nxt);
     for (const TBlock& t : f->up.tb) tblock(r, t, b, nxt, T, C, H);
-    r.gemm(f->up_conv2, nxt, C, M2, cur, C, 0, nullptr, 2, T);
+    r.gemm(f->up_conv2, nxt, C, T, cur, C, 0, nullptr, 2, 2);
     // final block + projection
-    r.gemm(f->final_conv, cur, C, M2, b.c1, C, 0, nullptr, 2, T);
+    r.gemm(f->final_conv, cur, C, T, b.c1, C, 0, nullptr, 2, 2);
     r.ln_mish(f->final_n, b.c1, nullptr, b.h1, M2, C);
     r.gemm(f->final_proj, b.h1, C, M2, b.d, M);
     hipLaunchKernelGGL(flow_euler, dim3(gTM), dim3(256), 0, s, b.d, b.xs, b.hin, T, M, dts[st], c.cfg_rate);
