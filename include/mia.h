@@ -89,6 +89,13 @@ int mia_logmel_whisper(mia_ctx* ctx, const float* pcm, const int64_t* offs, int 
 int mia_logmel_s3(mia_ctx* ctx, const float* pcm, const int64_t* offs, int B, int n_mels,
                   int64_t pad_right, int64_t n_frames_out, void* mel, int out_dtype, int mem);
 
+/* 80-bin 24 kHz log-mel of the CosyVoice2 / S3Gen prompt features.  Replaces s3genMelSpectrogram
+ * (Codec/S3Gen/Mel/S3GenMel.swift:43-102, called from TTS/CosyVoice2/CosyVoice2TTS.swift:370-430): reflect pad 720,
+ * n_fft 1920, hop 480, periodic Hann, |rfft|, slaney filterbank 0..8 kHz, natural log clamped at 1e-5.
+ *   pcm float32 mono 24 kHz [n_samples]; mel out float32 [80][mia_mel_s3gen_frames(n_samples)] (channel-major). */
+int64_t mia_mel_s3gen_frames(int64_t n_samples);
+int mia_mel_s3gen(mia_ctx* ctx, const float* pcm, int64_t n_samples, float* mel, int mem);
+
 /* ---- operator level -------------------------------------------------------------------------- */
 /* y = act(x W^T + b) + r : the dense contraction behind every MLXNN Linear on the path
  * (e.g. STT/Whisper/Layers/MultiHeadAttention.swift:40-58,134; ResidualAttentionBlock.swift:91).

@@ -88,3 +88,20 @@ def f32_to_bf16(a: np.ndarray) -> np.ndarray:
     u = np.ascontiguousarray(a, np.float32).view(np.uint32)
     r = ((u >> 16) & 1) + np.uint32(0x7FFF)
     return ((u + r) >> 16).astype(np.uint16)
+
+
+def s3gen_mel_spectrogram(ctx: _lib.Context, y) -> np.ndarray:
+    """s3genMelSpectrogram(y:) with its defaults (Codec/S3Gen/Mel/S3GenMel.swift:43-102): 24 kHz mono float32 [T] -> [80, frames]."""
+    import ctypes as C
+    lib = ctx.lib
+    if not getattr(lib, "_mel24_declared", False):
+        lib.mia_mel_s3gen_frames.restype = C.c_int64
+        lib.mia_mel_s3gen_frames.argtypes = [C.c_int64]
+        lib.mia_mel_s3gen.restype = C.c_int
+        lib.mia_mel_s3gen.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+        lib._mel24_declared = True
+    a = np.ascontiguousarray(y, np.float32).reshape(-1)
+    frames = max(int(lib.mia_mel_s3gen_frames(a.shape[0])), 0)
+    out = np.empty((80, frames), np.float32)
+    ctx.check(lib.mia_mel_s3gen(ctx.h, a.ctypes.data, a.shape[0], out.ctypes.data, _lib.MEM_HOST))
+    return out

@@ -1,4 +1,5 @@
 // mia_ctx.hip -- context lifecycle for the C ABI (include/mia.h).
+#include <cstdlib>
 #include "mia_internal.h"
 
 extern "C" const char* mia_version(void) { return "mia 0.1 (gfx950)"; }
@@ -46,6 +47,8 @@ extern "C" void mia_destroy(mia_ctx* ctx) {
     (void)hipFree(t.fb_w);
     (void)hipFree(t.fb_meta);
   }
+  for (void* p : ctx->table_allocs) (void)hipFree(p);
+  if (ctx->s3gen_mel) free(ctx->s3gen_mel);
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ws) (void)hipFree(ctx->ws);
@@ -112,6 +115,8 @@ extern "C" int mia_profile_enable(mia_ctx* ctx, int on) {
 extern "C" int mia_profile_reset(mia_ctx* ctx) {
   if (!ctx) return MIA_ERR_INVALID_ARGUMENT;
   MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (void* p : ctx->table_allocs) (void)hipFree(p);
+  if (ctx->s3gen_mel) free(ctx->s3gen_mel);
   for (auto& r : ctx->prof) { ctx->ev_pool.push_back(r.start); ctx->ev_pool.push_back(r.stop); }
   ctx->prof.clear();
   return MIA_OK;
@@ -124,6 +129,8 @@ extern "C" int mia_profile_read(mia_ctx* ctx, const char* kernel_class, int64_t*
   MIA_CHECK_ARG(ctx, cls >= 0, "profile_read: unknown kernel class '%s'", kernel_class);
   MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int64_t n = 0; double ms = 0.0, work = 0.0;
+  for (void* p : ctx->table_allocs) (void)hipFree(p);
+  if (ctx->s3gen_mel) free(ctx->s3gen_mel);
   for (auto& r : ctx->prof) {
     if (r.cls != cls) continue;
     float t = 0.f;

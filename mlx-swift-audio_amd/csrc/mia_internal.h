@@ -29,6 +29,8 @@ struct mia_ctx {
     int fb_nnz = 0;
   };
   std::vector<MelTables> mel_tables;
+  std::vector<void*> table_allocs;   // other cached device tables (freed at destroy), e.g. the 24 kHz 80-mel front end
+  void* s3gen_mel = nullptr;         // S3GenMelTables* (mel_s3gen.hip), lives in table_allocs' lifetime
   // optional HIP-event profiling of kernel classes (mia_profile_*): bench.py's roofline figures come from here
   bool prof_on = false;
   struct ProfRec { int cls; hipEvent_t start, stop; double work; };

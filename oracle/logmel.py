@@ -174,3 +174,16 @@ def synth_clip(i: int, n_samples: int = N_SAMPLES) -> np.ndarray:
     """SURVEY.md section 8d synthetic clip i (generator shared with the benchmark)."""
     from mlx_swift_audio_amd.synthetic import synth_clip as _sc
     return _sc(i, n_samples)
+
+
+def s3gen_mel_spectrogram(y: np.ndarray, n_fft: int = 1920, num_mels: int = 80, sampling_rate: int = 24000, hop_size: int = 480,
+                          win_size: int = 1920, fmin: float = 0.0, fmax: float = 8000.0) -> np.ndarray:
+    """Codec/S3Gen/Mel/S3GenMel.swift:43-102 -- reflect pad (n_fft - hop)/2, periodic Hann, |rfft| (center false), slaney
+    filterbank, log(max(., 1e-5)).  y [T] -> [num_mels, frames]."""
+    y = reflect_pad(np.asarray(y, f32), (n_fft - hop_size) // 2)
+    window = hanning_window(win_size + 1)[:win_size]
+    spec = stft(y, window, n_fft, hop_size, center=False)
+    mag = np.abs(spec).astype(f32)
+    filters = mel_filters(sampling_rate, n_fft, num_mels, fmin, fmax)
+    mel = (mag @ filters.T).astype(f32).T
+    return np.log(np.maximum(mel, f32(1e-5))).astype(f32)

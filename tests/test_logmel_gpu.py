@@ -104,3 +104,20 @@ def test_error_paths(ctx):
     assert e.value.code in (m._lib.ERR_INVALID_AUDIO,)
     with pytest.raises(m.MiaError):
         A.whisper_log_mel_spectrogram(ctx, O.synth_clip(0, 16000), 129)
+
+
+def test_s3gen_mel_24k(ctx):
+    """80-bin 24 kHz prompt-feature mel (S3GenMel.swift:43-102) against the oracle."""
+    from mlx_swift_audio_amd import audio as A
+    OL = O
+    rng = np.random.default_rng(11)
+    for n in (1200, 24000, 24000 * 6 + 77):
+        t = np.arange(n, dtype=np.float32) / 24000.0
+        y = (0.3 * np.sin(2 * np.pi * 220.0 * t) + 0.1 * np.sin(2 * np.pi * 3100.0 * t) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+        want = OL.s3gen_mel_spectrogram(y)
+        got = A.s3gen_mel_spectrogram(ctx, y)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, atol=2e-3, rtol=0)      # natural-log units; 1920-term fp32 sums
+    import mlx_swift_audio_amd as M
+    with pytest.raises(M.MiaError):
+        A.s3gen_mel_spectrogram(ctx, np.zeros(100, np.float32))
