@@ -1,0 +1,63 @@
+"""Host-side mirror of CosyVoice2Model (TTS/CosyVoice2/CosyVoice2Model.swift:28-208) and of the tensor part of
+prepareConditionals (TTS/CosyVoice2/CosyVoice2TTS.swift:370-430): generateTokens -> tokensToMel -> melToAudio, every stage on
+the gfx950 HIP layer.  Text tokenisation, resampling of the reference clip and the CAM++ speaker encoder stay with the caller
+(CPU text code / one-off per speaker), so text arrives as token ids and the speaker as its 192-d embedding.
+Every random draw of the reference is an explicit argument: `uniforms` (RAS sampler), `z` (CFM noise), `noise` (HiFT source)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class CosyVoice2Conditionals:
+    """CosyVoice2Conditionals (CosyVoice2Model.swift:557-575), tensors only."""
+    prompt_speech_token: np.ndarray      # int32 [m]
+    prompt_mel: np.ndarray               # float32 [2 m, 80] (time-major, as flow.inference consumes it)
+    speaker_embedding: np.ndarray        # float32 [192]
+    prompt_text: list[int]
+
+
+class CosyVoice2Model:
+    def __init__(self, ctx, llm, flow, hifigan, s3_tokenizer=None):
+        self.ctx, self.llm, self.flow, self.hifigan, self.s3 = ctx, llm, flow, hifigan, s3_tokenizer
+
+    # ---- prepareConditionals, tensor part (CosyVoice2TTS.swift:383-423) -------------------------------------------------------------
+    def prepare_conditionals(self, ref_wav_16k: np.ndarray, ref_wav_24k: np.ndarray, speaker_embedding: np.ndarray, prompt_text=()):
+        from . import audio as A
+        if self.s3 is None:
+            raise ValueError("CosyVoice2Model was built without an S3 tokenizer")
+        mel128 = A.s3_log_mel_spectrogram(self.ctx, np.ascontiguousarray(ref_wav_16k, np.float32), 128)
+        tk, nt = self.s3.quantize(mel128[None], np.asarray([mel128.shape[1]], np.int32))
+        toks = np.asarray(tk[0][:int(nt[0])], np.int32)
+        mel80 = A.s3gen_mel_spectrogram(self.ctx, ref_wav_24k).T                       # [frames, 80]
+        # the engine trims both so that mel frames == 2 * speech tokens (CosyVoice2TTS.swift:404-414)
+        n = min(mel80.shape[0] // 2, toks.shape[0])
+        return CosyVoice2Conditionals(toks[:n].copy(), np.ascontiguousarray(mel80[:2 * n]), np.ascontiguousarray(speaker_embedding, np.float32),
+                                      list(prompt_text))
+
+    # ---- the three stages (CosyVoice2Model.swift:53-133) ------------------------------------------------------------------------------
+    def generate_tokens(self, text, prompt_text, prompt_speech_token, uniforms, sampling: int = 25, max_token_text_ratio: float = 20.0,
+                        min_token_text_ratio: float = 2.0) -> list[int]:
+        return self.llm.inference(list(text), list(prompt_text), list(prompt_speech_token), uniforms, max_token_text_ratio=max_token_text_ratio,
+                                  min_token_text_ratio=min_token_text_ratio, top_k=sampling)
+
+    def tokens_to_mel(self, tokens, prompt_token, prompt_feat, embedding, z, n_timesteps: int | None = None) -> np.ndarray:
+        return self.flow.inference(tokens, prompt_token, prompt_feat, embedding, z, n_timesteps)
+
+    def mel_to_audio(self, mel: np.ndarray, noise=None) -> np.ndarray:
+        return self.hifigan(mel, noise=noise)[0]
+
+    # ---- synthesize (CosyVoice2Model.swift:155-208) --------------------------------------------------------------------------------------
+    def synthesize(self, text, cond: CosyVoice2Conditionals, uniforms, z_fn, noise_fn=None, sampling: int = 25, n_timesteps: int = 10,
+                   max_token_text_ratio: float = 20.0, min_token_text_ratio: float = 2.0):
+        """z_fn(T) -> [80, T] and noise_fn(L) -> [L, 9] supply the Gaussian draws once the generated length is known.
+        Returns (audio [480 * 2 * n_tokens], tokens)."""
+        tokens = self.generate_tokens(text, cond.prompt_text, cond.prompt_speech_token, uniforms, sampling, max_token_text_ratio, min_token_text_ratio)
+        if not tokens:
+            raise ValueError("No tokens generated")            # CosyVoice2Error.invalidInput (CosyVoice2Model.swift:182-184)
+        T = 2 * (len(tokens) + len(cond.prompt_speech_token))
+        mel = self.tokens_to_mel(np.asarray(tokens, np.int32), cond.prompt_speech_token, cond.prompt_mel, cond.speaker_embedding, z_fn(T), n_timesteps)
+        noise = noise_fn(mel.shape[1] * self.hifigan.up) if noise_fn is not None else None
+        return self.mel_to_audio(mel, noise), tokens

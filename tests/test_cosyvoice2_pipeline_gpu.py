@@ -1,0 +1,75 @@
+"""End-to-end CosyVoice2 chain on the GPU (SURVEY.md rows a15-a18 + the 24 kHz mel): reference clip -> S3 tokens + 80-mel prompt
+features -> Qwen2LM RAS token generation -> flow (conformer + CFM) -> HiFT vocoder, through the host mirror of CosyVoice2Model.
+Each hand-over is compared with the oracle of the stage that consumes it (the LM's sampled stream is checked in test_lm_gpu.py;
+here its output feeds the oracles so that one sampling fork cannot mask a later stage)."""
+import numpy as np
+import pytest
+
+from mlx_swift_audio_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+S_TOK = 6561
+
+
+def test_zero_shot_pipeline(ctx):
+    import dataclasses
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import cosyvoice2 as CV, flow as HF, hift as HH, lm as HL, s3tok as HS
+    from oracle import flow as OF, hift as OH, logmel as OL
+
+    lcfg = S.LM_CONFIGS["qwen-micro"]
+    lw = S.lm_weights(lcfg, seed=3, round_to="f16")
+    lw.update(S.qwen2lm_extra_weights(lcfg, S_TOK, seed=3, round_to="f16"))
+    llm = HL.Qwen2LM(HL.CausalLM.load(ctx, lcfg, lw, m.F16), lw, speech_token_size=S_TOK)
+    fcfg = dataclasses.replace(S.FLOW_CONFIGS["flow_micro"], vocab_size=S_TOK)
+    fw = S.flow_weights(fcfg, seed=3)
+    flow = HF.FlowModule.load(ctx, fcfg, fw)
+    hcfg = S.HIFT_CONFIGS["hift_micro"]
+    hw = S.hift_weights(hcfg, seed=3)
+    hift = HH.HiFTGenerator.load(ctx, hcfg, hw)
+    scfg = S.S3_CONFIGS["s3_micro"]
+    s3 = HS.S3Tokenizer.load(ctx, scfg, S.s3_weights(scfg, 3))
+    model = CV.CosyVoice2Model(ctx, llm, flow, hift, s3)
+
+    # ---- conditionals from a 2 s reference clip (the 24 kHz copy is an independent synthetic clip: resampling is the caller's)
+    ref16 = OL.synth_clip(1, 32000)
+    ref24 = OL.synth_clip(2, 48000)
+    rng = np.random.default_rng(0)
+    spk = rng.standard_normal(fcfg.spk_embed_dim).astype(np.float32)
+    cond = model.prepare_conditionals(ref16, ref24, spk, prompt_text=[7, 8, 9])
+    n_p = cond.prompt_speech_token.shape[0]
+    assert n_p == 50 and cond.prompt_mel.shape == (2 * n_p, 80)          # 2 s -> 50 tokens @ 25 Hz, 100 mel frames @ 50 Hz
+    np.testing.assert_allclose(cond.prompt_mel, OL.s3gen_mel_spectrogram(ref24).T[:2 * n_p], atol=2e-3)
+
+    # ---- synthesize
+    text = [21, 22, 23, 24, 25, 26, 27, 28]
+    u = rng.random(4000).astype(np.float32)
+    draws = {}
+
+    def z_fn(T):
+        draws["z"] = np.random.default_rng(1).standard_normal((80, T)).astype(np.float32)
+        return draws["z"]
+
+    def noise_fn(L):
+        draws["noise"] = np.random.default_rng(2).standard_normal((L, 9)).astype(np.float32)
+        return draws["noise"]
+
+    audio, tokens = model.synthesize(text, cond, u, z_fn, noise_fn)
+    assert len(text) * 2 - 1 <= len(tokens) <= len(text) * 20 and all(0 <= t < S_TOK for t in tokens)
+    assert audio.shape == (2 * len(tokens) * 480,) and np.isfinite(audio).all() and np.abs(audio).max() <= 0.99 + 1e-7
+
+    # ---- stage-wise parity on the same hand-overs
+    mel = model.tokens_to_mel(np.asarray(tokens, np.int32), cond.prompt_speech_token, cond.prompt_mel, cond.speaker_embedding, draws["z"])
+    want_mel, _ = OF.inference(fw, fcfg, np.asarray(tokens), cond.prompt_speech_token, cond.prompt_mel, cond.speaker_embedding, draws["z"])
+    np.testing.assert_allclose(mel, want_mel, atol=2e-3, rtol=2e-3)
+    want_audio, want_src = OH.vocode(hw, hcfg, mel, draws["noise"])
+    np.testing.assert_allclose(audio, want_audio, atol=3e-2)                # f0 rounding moves the source phase (see test_hift_gpu.py)
+    pinned, _ = hift(mel, cache_source=want_src, noise=draws["noise"])
+    np.testing.assert_allclose(pinned, want_audio, atol=3e-4, rtol=1e-3)
+    again, tokens2 = model.synthesize(text, cond, u, z_fn, noise_fn)
+    assert tokens2 == tokens
+    np.testing.assert_array_equal(again, audio)
+    for h in (flow, hift, s3):
+        h.close()
+    llm.lm.close()
