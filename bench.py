@@ -291,6 +291,17 @@ def main():
                     "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
                     "traffic": None, "launches": int(steps_d), "avg_launch_ms": round(ms_d / max(steps_d, 1), 4),
                     "bytes_per_launch": dec_bytes_per_step}
+    # HBM traffic per launch from the committed PMC passes of this same workload (rocprofv3 cannot run inside the timed process):
+    # profiles/r01_pmc_summary.json, made by tools/pmc_summary.py with the guide's gfx950 corrections.  null when absent.
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")))
+        if roofline["bound"] == "hbm":
+            roofline["traffic"] = round(pmc["decode_step"]["hbm_bytes_per_step"], 0)
+        else:
+            roofline["traffic"] = round(pmc["encoder_gemm"]["hbm_bytes_per_launch"], 0)
+        roofline["traffic_source"] = "profiles/r01_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
+    except (OSError, KeyError, ValueError):
+        pass
     stage = {k: {"ms_per_step": round(v[1] / args.steps, 3), "share": round(shares[k], 4)} for k, v in prof.items()}
     stage["enc_gemm"]["tflops"] = round(gemm_tflops, 1)
     if prof["enc_attention"][0]:
