@@ -120,14 +120,18 @@ __global__ __launch_bounds__(256) void dec_reduce_ln(const float* __restrict__ p
 // ------------------------------------------------------------------------------------------------
 // NT = 16-column tiles per wave (activation fragments are reused NT times: NT=4 for the 51866-wide logits GEMM,
 // where the L2->CU activation traffic would otherwise be twice the HBM weight traffic); KB = K-steps per batch.
-template <typename T, int MODE, int NT, int KB>
-__global__ __launch_bounds__(64) void dec_skinny_gemm(SkinnyArgs a) {
-  const int lane = threadIdx.x;
+// NW = waves per workgroup, each taking 1/NW of the K range (intra-block split-K, summed through LDS in wave order: deterministic).
+// With one wave per CU the weight stream is latency-bound (12 KB in flight per CU); NW = 4 quadruples the loads in flight.
+// (Cross-workgroup tickets were tried for fusing the split-K reduction + LayerNorm into this kernel: same-address device-scope atomics
+// from ~640 workgroups on 8 XCDs cost ~60 us per launch -- far more than the 5 us kernel boundary they would remove.)
+template <typename T, int MODE, int NT, int KB, int NW>
+__global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * (16 * NT);
   const int split = blockIdx.y;
   const int m0 = blockIdx.z * 32;
-  const int Kc = a.K / a.S;
-  const int kbeg = split * Kc;
+  const int Kc = a.K / (a.S * NW);
+  const int kbeg = (split * NW + wave) * Kc;
   const int r = lane & 15, c = lane >> 4;
   const uint16_t* wp[NT];
 #pragma unroll
@@ -197,6 +201,27 @@ __global__ __launch_bounds__(64) void dec_skinny_gemm(SkinnyArgs a) {
       acc[n][0] = T::mfma16(fw, fa0, acc[n][0]);
       acc[n][1] = T::mfma16(fw, fa1, acc[n][1]);
     }
+  }
+  if (NW > 1) {   // fixed-order cross-wave sum: waves 1.. park their fragments in LDS, wave 0 adds them in wave order
+    __shared__ f32x4 red[(NW > 1 ? NW - 1 : 1) * NT * 2 * 64];
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) red[(((wave - 1) * NT + t) * 2 + mt) * 64 + lane] = acc[t][mt];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w2 = 1; w2 < NW; ++w2)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const f32x4 o = red[(((w2 - 1) * NT + t) * 2 + mt) * 64 + lane];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[t][mt][j] += o[j];
+        }
   }
   // lane holds C[m = m0 + mt*16 + r][n = n0 + 16t + 4c + j]
 #pragma unroll
@@ -603,19 +628,26 @@ int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln
 
 template <typename T>
 static void skinny_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
-  dim3 block(64);
   if (mode == SK_OUTF32) {   // the vocabulary-wide logits GEMM: 64 columns per wave
     dim3 grid((a.N + 63) / 64, a.S, (a.M + 31) / 32);
-    hipLaunchKernelGGL((dec_skinny_gemm<T, SK_OUTF32, 4, 2>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((dec_skinny_gemm<T, SK_OUTF32, 4, 2, 1>), grid, dim3(64), 0, s, a);
     return;
   }
   dim3 grid((a.N + 15) / 16, a.S, (a.M + 31) / 32);
+  // few workgroups and a long K per wave -> split K over 4 waves of the workgroup (K per wave stays a multiple of 32)
+  const bool wide = (int64_t)grid.x * grid.y * grid.z <= 1024 && a.K % (128 * a.S) == 0 && a.K / a.S >= 512;
+#define SK_LAUNCH(MODE_)                                                                                              \
+  do {                                                                                                                \
+    if (wide) hipLaunchKernelGGL((dec_skinny_gemm<T, MODE_, 1, 2, 4>), grid, dim3(256), 0, s, a);                      \
+    else hipLaunchKernelGGL((dec_skinny_gemm<T, MODE_, 1, 4, 1>), grid, dim3(64), 0, s, a);                            \
+  } while (0)
   switch (mode) {
-    case SK_OUT16: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_OUT16, 1, 4>), grid, block, 0, s, a); break;
-    case SK_PARTIAL: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_PARTIAL, 1, 4>), grid, block, 0, s, a); break;
-    case SK_SWIGLU: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_SWIGLU, 1, 4>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((dec_skinny_gemm<T, SK_QKV, 1, 4>), grid, block, 0, s, a); break;
+    case SK_OUT16: SK_LAUNCH(SK_OUT16); break;
+    case SK_PARTIAL: SK_LAUNCH(SK_PARTIAL); break;
+    case SK_SWIGLU: SK_LAUNCH(SK_SWIGLU); break;
+    default: SK_LAUNCH(SK_QKV); break;
   }
+#undef SK_LAUNCH
 }
 
 int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) {
