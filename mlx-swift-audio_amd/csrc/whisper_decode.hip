@@ -26,7 +26,7 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p) {
     SkinnyArgs a{A, lda, (const uint16_t*)lw.w, use_bias ? lw.b : nullptr, out, ldo, ck, cv, w->clip.pos, B, lw.N, lw.K, S, act, D, H, C};
     return dec_launch_skinny(w, a, mode, s);
   };
-  const int S_d = pick_split(D, 8), S_4d = pick_split(4 * D, 16);
+  const int S_d = pick_split(D, 2), S_4d = pick_split(4 * D, 4);   // x 4 waves of intra-workgroup split-K each
   dec_launch_embed_ln(w, w->dec[0].attn_ln, s);
   for (int l = 0; l < p.L; ++l) {
     const DecBlockW& b = w->dec[l];
