@@ -28,11 +28,13 @@ __device__ __forceinline__ float snake_p(float x, float a, float ra) {
   return x + ra * (s * s);
 }
 
-constexpr int GBM = 128, GBK = 32, GSTR = GBK + 1;   // LDS row stride 33 floats: conflict-free column reads
+constexpr int GBK = 32, GSTR = GBK + 1;   // LDS row stride 33 floats: conflict-free column reads
 
-// WN = 32-column MFMA tiles per wave along N (2 -> 128-wide block tile, 1 -> 64-wide)
-template <int WN>
+// WM / WN = 32-row / 32-column MFMA tiles per wave (4 waves as 2 x 2): block tile (64 WM) x (64 WN).  <2,2> = 128 x 128 for large
+// problems, <2,1> = 128 x 64 for narrow outputs, <1,1> = 64 x 64 when 128-row tiles would leave most of the 256 CUs idle.
+template <int WM, int WN>
 __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
+  constexpr int GBM = 64 * WM;
   constexpr int GBN = 64 * WN;
   __shared__ float As[GBM * GSTR];
   __shared__ float Bs[GBN * GSTR];
@@ -45,9 +47,9 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   const int Ktot = g.taps * g.Cin;
   const int64_t ldw = g.ldw > 0 ? g.ldw : Ktot;
 
-  // staging coordinates: A: 4 rows x float4 per thread, B: WN*2 rows x float4 per thread
+  // staging coordinates: A: 2 WM rows x float4 per thread, B: 2 WN rows x float4 per thread
   const int s_row = tid >> 3, s_col = (tid & 7) * 4;
-  float4 ra[4], rb[2 * WN];
+  float4 ra[2 * WM], rb[2 * WN];
   auto load_tiles = [&](int k0) {
     const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin + s_col;
     float al[4] = {0.f, 0.f, 0.f, 0.f}, ral[4] = {0.f, 0.f, 0.f, 0.f};
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
       for (int j = 0; j < 4; ++j) { al[j] = g.alpha[c0 + j]; ral[j] = g.ralpha ? g.ralpha[c0 + j] : 1.0f / (al[j] + 1e-9f); }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2 * WM; ++i) {
       const int m = m0 + s_row + 32 * i;
       const int xr = m * g.x_row_mul + tap * g.dil - g.pad;    // host checks that M * x_row_mul fits 31 bits
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2 * WM; ++i) {
       float* d = As + (s_row + 32 * i) * GSTR + s_col;
       d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
     }
@@ -91,15 +93,15 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
     }
   };
 
-  f32x16 acc[2][WN];
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int a_off = (wr * 64 + (lane & 31)) * GSTR + (lane >> 5);
+  const int a_off = (wr * 32 * WM + (lane & 31)) * GSTR + (lane >> 5);
   const int b_off = (wc * 32 * WN + (lane & 31)) * GSTR + (lane >> 5);
   const int nk = Ktot / GBK;
   load_tiles(0);
@@ -110,13 +112,13 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
     if (kt + 1 < nk) load_tiles((kt + 1) * GBK);   // global loads fly under the MFMAs below
 #pragma unroll 4
     for (int kk = 0; kk < GBK; kk += 2) {
-      float a[2], b[WN];
+      float a[WM], b[WN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[a_off + i * 32 * GSTR + kk];
+      for (int i = 0; i < WM; ++i) a[i] = As[a_off + i * 32 * GSTR + kk];
 #pragma unroll
       for (int j = 0; j < WN; ++j) b[j] = Bs[b_off + j * 32 * GSTR + kk];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
@@ -128,10 +130,10 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
     if (n >= g.N) continue;
     const float bias = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + wr * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= g.M) continue;
         const int64_t yr = (int64_t)m * g.y_row_mul + g.y_row_off + (int64_t)z * g.y_phase_step;
         if (yr < 0 || yr >= g.T_out) continue;
@@ -260,12 +262,17 @@ const char* codec_conv_gemm_check(const ConvGemmArgs& g) {
 }
 
 int codec_conv_gemm_launch(const ConvGemmArgs& g, int phases, hipStream_t s) {
-  if (g.N > 64) {
-    dim3 grid((g.M + GBM - 1) / GBM, (g.N + 127) / 128, phases);
-    hipLaunchKernelGGL(conv_gemm_f32<2>, grid, dim3(256), 0, s, g);
+  // 128-row tiles only when they still give every CU work; otherwise 64 x 64 tiles (4x the workgroups)
+  const int64_t big_blocks = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * phases;
+  if (big_blocks < 384) {
+    dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, phases);
+    hipLaunchKernelGGL((conv_gemm_f32<1, 1>), grid, dim3(256), 0, s, g);
+  } else if (g.N > 64) {
+    dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, phases);
+    hipLaunchKernelGGL((conv_gemm_f32<2, 2>), grid, dim3(256), 0, s, g);
   } else {
-    dim3 grid((g.M + GBM - 1) / GBM, (g.N + 63) / 64, phases);
-    hipLaunchKernelGGL(conv_gemm_f32<1>, grid, dim3(256), 0, s, g);
+    dim3 grid((g.M + 127) / 128, (g.N + 63) / 64, phases);
+    hipLaunchKernelGGL((conv_gemm_f32<2, 1>), grid, dim3(256), 0, s, g);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
