@@ -105,6 +105,13 @@ int mia_mel_s3gen(mia_ctx* ctx, const float* pcm, int64_t n_samples, float* mel,
 int mia_op_linear(mia_ctx* ctx, const void* x, int64_t lda, const void* w, const float* bias, const float* r, int64_t ldr,
                   void* y, int64_t ldy, int M, int N, int K, int act, int dtype, int out_f32, int variant, int mem);
 
+/* fp32 Conv1d / Linear, the contraction behind every MLXNN Conv1d / Linear of the codec, flow and vocoder stages
+ * (e.g. Codec/S3Gen/S3GenDecoder.swift:40-48, Codec/S3Gen/Matcha/MatchaTransformer.swift:36-56), time-major, DEVICE pointers:
+ *   y[t][n] = act(b[n] + sum_{k,c} x[t*stride + k*dil - pad][c] * w[n][k][c]) (+ r[t][n]);  x [T_in][ldx], w [N][taps][Cin] (Cin % 32 == 0),
+ *   act 0 none / 1 exact-erf GELU / 2 ELU / 3 abs / 4 SiLU / 5 leaky-ReLU(0.01).  Rows outside [0, T_in) read as zero. */
+int mia_op_conv1d_f32(mia_ctx* ctx, const float* x, int64_t ldx, int T_in, const float* w, const float* bias, const float* r, float* y,
+                      int64_t ldy, int T_out, int N, int Cin, int taps, int stride, int dil, int pad, int act);
+
 /* ---- Whisper ---------------------------------------------------------------------------------- */
 /* Model dimensions == ModelDimensions (STT/Whisper/Config/WhisperConfig.swift:9-86), read by the caller
  * from config.json. */

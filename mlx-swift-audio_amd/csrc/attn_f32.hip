@@ -7,11 +7,13 @@
 // term is one more 64-wide contraction against per-position keys: the POS variant runs the QK product over the concatenated
 // 128-wide operands [q + u | q + v] . [k | p].
 //
-// One 256-thread workgroup = 128 queries of one (batch, head); one wave = 32 queries.  S^T = K Q^T on v_mfma_f32_32x32x2_f32, so
+// One 256-thread workgroup = 64 queries of one (batch, head): 2 query groups of 32 x 2 halves of the key range (split-KV).  S^T = K Q^T on v_mfma_f32_32x32x2_f32, so
 // a lane owns ONE query column and 16 keys of it: the online softmax is in-lane plus one cross-half shuffle, and the S^T
 // accumulator registers are, in order, the B operand of O^T += V^T P^T (the A operand reads V rows in the matching key order).
 // K / P / V tiles of 32 keys are staged HBM -> registers -> LDS with row strides (66 | 130, 72 floats) that make every
 // fragment read bank-conflict free.
+#include <cstdlib>
+
 #include "mia_device.h"
 #include "ops.h"
 
@@ -22,14 +24,19 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
   constexpr int DQK = POS ? 128 : 64;
   constexpr int SK = DQK + 2;       // K row stride (floats): 2*key + half distinct mod 64
   constexpr int SV = 72;            // V row stride: keys k and k+4 land 32 banks apart
-  __shared__ __attribute__((aligned(16))) float Ks[32 * SK];
-  __shared__ __attribute__((aligned(16))) float Vs[32 * SV];
+  // two KV tiles per iteration: waves 0,1 (query groups 0,1) walk the even tiles, waves 2,3 the odd ones (split-KV inside the
+  // workgroup: the per-wave chain of dependent MFMAs -- the latency that bounds this kernel -- is halved); merged through LDS.
+  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * SK + 2 * 32 * SV];   // K tiles | V tiles; reused for the final merge
+  float (*Ks)[32 * SK] = reinterpret_cast<float (*)[32 * SK]>(lds);
+  float (*Vs)[32 * SV] = reinterpret_cast<float (*)[32 * SV]>(lds + 2 * 32 * SK);
+  static_assert(2 * 64 * 34 <= 2 * 32 * SK + 2 * 32 * SV, "merge buffer must fit in the tile storage");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qg = wave & 1, kvh = wave >> 1;
   const int lq = lane & 31, lh = lane >> 5;
-  const int nqb = (a.T + 127) / 128;
+  const int nqb = (a.T + 63) / 64;
   const int qb = blockIdx.x % nqb, hb = blockIdx.x / nqb;
   const int h = hb % a.H, b = hb / a.H;
-  const int q0 = qb * 128 + wave * 32;
+  const int q0 = qb * 64 + qg * 32;
   const float* Q = a.q + (int64_t)b * a.T * a.ldq + h * 64;
   const float* K = a.k + (int64_t)b * a.T * a.ldk + h * 64;
   const float* V = a.v + (int64_t)b * a.T * a.ldv + h * 64;
@@ -54,30 +61,30 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     }
   }
 
-  // ---- staging: tile = 32 keys x 64 floats = 512 float4, 2 per thread per source
-  const int s_row = tid >> 4, s_c4 = (tid & 15) * 4;      // rows s_row and s_row + 16
-  float4 rk[2], rp[2], rv[2];
+  // ---- staging: 2 tiles x 32 keys x 64 floats = 1024 float4 per source, 4 per thread: thread -> (tile = tid >> 7, row pair, 16-B column)
+  const int s_tile = tid >> 7, s_row = (tid & 127) >> 4, s_c4 = (tid & 15) * 4;      // rows s_row + 8 j, j = 0..3
+  float4 rk[4], rp[4], rv[4];
   auto load_regs = [&](int key0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = key0 + s_row + 16 * i; key = key < a.T ? key : a.T - 1;
-      rk[i] = *reinterpret_cast<const float4*>(K + (int64_t)key * a.ldk + s_c4);
-      rv[i] = *reinterpret_cast<const float4*>(V + (int64_t)key * a.ldv + s_c4);
-      if (POS) rp[i] = *reinterpret_cast<const float4*>(P + (int64_t)key * a.ldp + s_c4);
+    for (int j = 0; j < 4; ++j) {
+      int key = key0 + 32 * s_tile + s_row + 8 * j; key = key < a.T ? key : a.T - 1;
+      rk[j] = *reinterpret_cast<const float4*>(K + (int64_t)key * a.ldk + s_c4);
+      rv[j] = *reinterpret_cast<const float4*>(V + (int64_t)key * a.ldv + s_c4);
+      if (POS) rp[j] = *reinterpret_cast<const float4*>(P + (int64_t)key * a.ldp + s_c4);
     }
   };
   auto write_lds = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = s_row + 16 * i;
-      float* kd = Ks + row * SK + s_c4;                     // rows are 8-byte aligned only
-      *reinterpret_cast<float2*>(kd) = make_float2(rk[i].x, rk[i].y);
-      *reinterpret_cast<float2*>(kd + 2) = make_float2(rk[i].z, rk[i].w);
+    for (int j = 0; j < 4; ++j) {
+      const int row = s_row + 8 * j;
+      float* kd = Ks[s_tile] + row * SK + s_c4;              // rows are 8-byte aligned only
+      *reinterpret_cast<float2*>(kd) = make_float2(rk[j].x, rk[j].y);
+      *reinterpret_cast<float2*>(kd + 2) = make_float2(rk[j].z, rk[j].w);
       if (POS) {
-        *reinterpret_cast<float2*>(kd + 64) = make_float2(rp[i].x, rp[i].y);
-        *reinterpret_cast<float2*>(kd + 66) = make_float2(rp[i].z, rp[i].w);
+        *reinterpret_cast<float2*>(kd + 64) = make_float2(rp[j].x, rp[j].y);
+        *reinterpret_cast<float2*>(kd + 66) = make_float2(rp[j].z, rp[j].w);
       }
-      *reinterpret_cast<float4*>(Vs + row * SV + s_c4) = rv[i];
+      *reinterpret_cast<float4*>(Vs[s_tile] + row * SV + s_c4) = rv[j];
     }
   };
 
@@ -88,32 +95,51 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     for (int r = 0; r < 16; ++r) acc_o[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (a.T + 31) / 32;
+  const int npairs = (a.T + 63) / 64;
   load_regs(0);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int key0 = kt * 32;
-    __syncthreads();                 // previous tile fully consumed
-    write_lds();
+  for (int kp = 0; kp < npairs; ++kp) {
+    const int key0 = kp * 64 + 32 * kvh;          // this wave's tile
+    __syncthreads();                              // previous tiles fully consumed
+    if (!(a.dbg & 8) || kp == 0) write_lds();
     __syncthreads();
-    if (kt + 1 < ntiles) load_regs(key0 + 32);
+    if (kp + 1 < npairs && !(a.dbg & 4)) load_regs((kp + 1) * 64);
+    if (key0 >= a.T) continue;                    // odd tail tile absent (wave-uniform)
 
     // ---- S^T = K Q^T
     f32x16 acc_s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
-    const float* kp = Ks + lq * SK + lh;
+    // LDS operand reads are batched 8 MFMA steps ahead (sched_barrier keeps the compiler from sinking each read next to its MFMA,
+    // which exposed the full LDS latency on every one of the dependent MFMAs)
+    const float* kp_ = Ks[kvh] + lq * SK + lh;
+    {
+      constexpr int NB = DQK / 16;
+      float kf[2][8];
 #pragma unroll
-    for (int i = 0; i < DQK / 2; ++i) acc_s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * i], qf[i], acc_s, 0, 0, 0);
+      for (int u = 0; u < 8; ++u) kf[0][u] = kp_[2 * u];
+#pragma unroll
+      for (int bq = 0; bq < ((a.dbg & 1) ? 1 : NB); ++bq) {
+        const int cur = bq & 1;
+        if (bq + 1 < NB) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) kf[cur ^ 1][u] = kp_[2 * (8 * (bq + 1) + u)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc_s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[cur][u], qf[8 * bq + u], acc_s, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 
     // ---- online softmax (base 2): lane = one query, registers = keys (r&3) + 8 (r>>2) + 4 lh
     float mloc = -INFINITY;
     const bool tail = key0 + 32 > a.T;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float s = acc_s[r];
-      if (tail && key0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.T) s = -INFINITY;
-      acc_s[r] = s;
-      mloc = fmaxf(mloc, s);
+      float sv = acc_s[r];
+      if (tail && key0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.T) sv = -INFINITY;
+      acc_s[r] = sv;
+      mloc = fmaxf(mloc, sv);
     }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc);
@@ -133,25 +159,60 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
       for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
 
     // ---- O^T += V^T P^T: step j contracts key (j&3) + 8 (j>>2) + 4 lh
+    {
+      const float* vbase = Vs[kvh] + 4 * lh * SV + lq;
+      float vf[2][4][2];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float* vp = Vs + ((j & 3) + 8 * (j >> 2) + 4 * lh) * SV + lq;
-      acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], acc_s[j], acc_o[0], 0, 0, 0);
-      acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], acc_s[j], acc_o[1], 0, 0, 0);
+      for (int u = 0; u < 4; ++u) { vf[0][u][0] = vbase[u * SV]; vf[0][u][1] = vbase[u * SV + 32]; }
+#pragma unroll
+      for (int bq = 0; bq < ((a.dbg & 2) ? 1 : 4); ++bq) {       // batch bq = steps j = 4 bq .. 4 bq + 3 = key rows 8 bq + (0..3) + 4 lh
+        const int cur = bq & 1;
+        if (bq + 1 < 4) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { vf[cur ^ 1][u][0] = vbase[(8 * (bq + 1) + u) * SV]; vf[cur ^ 1][u][1] = vbase[(8 * (bq + 1) + u) * SV + 32]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][u][0], acc_s[4 * bq + u], acc_o[0], 0, 0, 0);
+          acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][u][1], acc_s[4 * bq + u], acc_o[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
-  l_run += __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_run;
-  const int q = q0 + lq;
-  if (q < a.T) {
-    float* op = a.out + ((int64_t)b * a.T + q) * a.ldo + h * 64 + 4 * lh;
+  // ---- merge the two KV halves (fixed order: even tiles' state + odd tiles' state), normalise, store
+  l_run += __shfl_xor(l_run, 32, 64);             // row sum over this wave's keys, in both lane halves
+  __syncthreads();                                // K / V tiles are dead: reuse Ks as the hand-over buffer
+  float* mb = lds + (qg * 64 + lane) * 34;        // [2 groups][64 lanes][m, l, 32 x o]
+  if (kvh == 1) {
+    mb[0] = m_run; mb[1] = l_run;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(op + db * 32 + 8 * g) =
-            make_float4(acc_o[db][4 * g] * inv, acc_o[db][4 * g + 1] * inv, acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv);
+      for (int r = 0; r < 16; ++r) mb[2 + db * 16 + r] = acc_o[db][r];
+  }
+  __syncthreads();
+  if (kvh == 1) return;
+  {
+    const float m1 = mb[0], l1 = mb[1];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
+    const float inv = 1.0f / (l_run * a0 + l1 * a1);
+    const int q = q0 + lq;
+    if (q < a.T) {
+      float* op = a.out + ((int64_t)b * a.T + q) * a.ldo + h * 64 + 4 * lh;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (acc_o[db][4 * g + e] * a0 + mb[2 + db * 16 + 4 * g + e] * a1) * inv;
+          *reinterpret_cast<float4*>(op + db * 32 + 8 * g) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
   }
 }
 
@@ -166,8 +227,11 @@ const char* mia_attn_f32_check(const AttnF32Args& a) {
   return nullptr;
 }
 
-int mia_attn_f32_launch(const AttnF32Args& a, hipStream_t s) {
-  dim3 grid(((a.T + 127) / 128) * a.H * a.B), block(256);
+int mia_attn_f32_launch(const AttnF32Args& a_in, hipStream_t s) {
+  AttnF32Args a = a_in;
+  static const char* dbg_env = getenv("MIA_ATTN_DBG");
+  if (dbg_env) a.dbg = atoi(dbg_env);
+  dim3 grid(((a.T + 63) / 64) * a.H * a.B), block(256);
   if (a.p) hipLaunchKernelGGL(attn_f32_kernel<true>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(attn_f32_kernel<false>, grid, block, 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -28,14 +28,17 @@ __device__ __forceinline__ float snake_p(float x, float a, float ra) {
   return x + ra * (s * s);
 }
 
-constexpr int GBK = 32, GSTR = GBK + 1;   // LDS row stride 33 floats: conflict-free column reads
 
 // WM / WN = 32-row / 32-column MFMA tiles per wave (4 waves as 2 x 2): block tile (64 WM) x (64 WN).  <2,2> = 128 x 128 for large
 // problems, <2,1> = 128 x 64 for narrow outputs, <1,1> = 64 x 64 when 128-row tiles would leave most of the 256 CUs idle.
-template <int WM, int WN>
+// KC = 32-wide K chunks per pipeline stage: the next stage's global loads are issued before the MFMAs of the current one, so a stage
+// must hold more MFMA time than one HBM / L2 round trip -- with 64 x 64 tiles a 32-wide stage is only 0.4 us of MFMAs (measured:
+// 3.5x slower than the MFMA bound), hence KC = 4 there.  A chunk never straddles a tap (Cin % 32 == 0); chunks past K are zero.
+template <int WM, int WN, int KC>
 __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   constexpr int GBM = 64 * WM;
   constexpr int GBN = 64 * WN;
+  constexpr int GBK = 32 * KC, GSTR = GBK + 1;   // LDS row stride odd: conflict-free column reads
   __shared__ float As[GBM * GSTR];
   __shared__ float Bs[GBN * GSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,23 +50,53 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   const int Ktot = g.taps * g.Cin;
   const int64_t ldw = g.ldw > 0 ? g.ldw : Ktot;
 
-  // staging coordinates: A: 2 WM rows x float4 per thread, B: 2 WN rows x float4 per thread
+  // staging coordinates: per chunk, A: 2 WM rows x float4 per thread, B: 2 WN rows x float4 per thread.
+  // Loads are UNCONDITIONAL (row / column indices clamped into the tensors) and the out-of-range zeroing plus the snake / leaky-ReLU
+  // prologue are applied when the registers are written to LDS: a predicated load (`if (ok) v = load`) makes the compiler drain
+  // vmcnt between consecutive loads, which serialised the 4-8 loads of a stage on their full memory latency.
   const int s_row = tid >> 3, s_col = (tid & 7) * 4;
-  float4 ra[2 * WM], rb[2 * WN];
-  auto load_tiles = [&](int k0) {
-    const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin + s_col;
-    float al[4] = {0.f, 0.f, 0.f, 0.f}, ral[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.alpha) {
+  float4 ra[KC][2 * WM], rb[KC][2 * WN];
+  uint32_t amask = 0, bmask = 0;            // bit (ch * 8 + i): element is inside the tensor
+  int kcur = 0;                             // K offset of the stage held in ra / rb
+  auto load_tiles = [&](int kbase) {
+    kcur = kbase; amask = 0; bmask = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { al[j] = g.alpha[c0 + j]; ral[j] = g.ralpha ? g.ralpha[c0 + j] : 1.0f / (al[j] + 1e-9f); }
+    for (int ch = 0; ch < KC; ++ch) {
+      int k0 = kbase + 32 * ch;
+      const bool kin = k0 < Ktot;
+      k0 = kin ? k0 : Ktot - 32;
+      const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin + s_col;
+#pragma unroll
+      for (int i = 0; i < 2 * WM; ++i) {
+        const int m = m0 + s_row + 32 * i;
+        const int xr = m * g.x_row_mul + tap * g.dil - g.pad;    // host checks that M * x_row_mul fits 31 bits
+        const bool ok = kin && m < g.M && xr >= 0 && xr < g.T_in;
+        const int xc = xr < 0 ? 0 : (xr < g.T_in ? xr : g.T_in - 1);
+        ra[ch][i] = *reinterpret_cast<const float4*>(X + (int64_t)xc * g.ldx + c0);
+        amask |= (ok ? 1u : 0u) << (ch * 8 + i);
+      }
+#pragma unroll
+      for (int i = 0; i < 2 * WN; ++i) {
+        const int n = n0 + s_row + 32 * i;
+        const int nc = n < g.N ? n : g.N - 1;
+        rb[ch][i] = *reinterpret_cast<const float4*>(W + (int64_t)nc * ldw + k0 + s_col);
+        bmask |= ((kin && n < g.N) ? 1u : 0u) << (ch * 8 + i);
+      }
     }
+  };
+  auto store_tiles = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2 * WM; ++i) {
-      const int m = m0 + s_row + 32 * i;
-      const int xr = m * g.x_row_mul + tap * g.dil - g.pad;    // host checks that M * x_row_mul fits 31 bits
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < g.M && xr >= 0 && xr < g.T_in) {
-        v = *reinterpret_cast<const float4*>(X + (int64_t)xr * g.ldx + c0);
+    for (int ch = 0; ch < KC; ++ch) {
+      float al[4] = {0.f, 0.f, 0.f, 0.f}, ral[4] = {0.f, 0.f, 0.f, 0.f};
+      if (g.alpha) {
+        int k0 = kcur + 32 * ch; k0 = k0 < Ktot ? k0 : Ktot - 32;
+        const int c0 = k0 % g.Cin + s_col;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { al[j] = g.alpha[c0 + j]; ral[j] = g.ralpha ? g.ralpha[c0 + j] : 1.0f / (al[j] + 1e-9f); }
+      }
+#pragma unroll
+      for (int i = 0; i < 2 * WM; ++i) {
+        float4 v = ra[ch][i];
         if (g.alpha) {
           v.x = snake_p(v.x, al[0], ral[0]); v.y = snake_p(v.y, al[1], ral[1]);
           v.z = snake_p(v.z, al[2], ral[2]); v.w = snake_p(v.w, al[3], ral[3]);
@@ -71,25 +104,17 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
           v.x = v.x > 0.f ? v.x : v.x * g.lrelu_slope; v.y = v.y > 0.f ? v.y : v.y * g.lrelu_slope;
           v.z = v.z > 0.f ? v.z : v.z * g.lrelu_slope; v.w = v.w > 0.f ? v.w : v.w * g.lrelu_slope;
         }
+        if (!((amask >> (ch * 8 + i)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d = As + (s_row + 32 * i) * GSTR + 32 * ch + s_col;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       }
-      ra[i] = v;
-    }
 #pragma unroll
-    for (int i = 0; i < 2 * WN; ++i) {
-      const int n = n0 + s_row + 32 * i;
-      rb[i] = n < g.N ? *reinterpret_cast<const float4*>(W + (int64_t)n * ldw + k0 + s_col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto store_tiles = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2 * WM; ++i) {
-      float* d = As + (s_row + 32 * i) * GSTR + s_col;
-      d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
-    }
-#pragma unroll
-    for (int i = 0; i < 2 * WN; ++i) {
-      float* d = Bs + (s_row + 32 * i) * GSTR + s_col;
-      d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
+      for (int i = 0; i < 2 * WN; ++i) {
+        float4 v = rb[ch][i];
+        if (!((bmask >> (ch * 8 + i)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d = Bs + (s_row + 32 * i) * GSTR + 32 * ch + s_col;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
     }
   };
 
@@ -103,24 +128,40 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
 
   const int a_off = (wr * 32 * WM + (lane & 31)) * GSTR + (lane >> 5);
   const int b_off = (wc * 32 * WN + (lane & 31)) * GSTR + (lane >> 5);
-  const int nk = Ktot / GBK;
+  const int nk = (Ktot + GBK - 1) / GBK;
   load_tiles(0);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();                       // previous tile fully consumed
     store_tiles();
     __syncthreads();
     if (kt + 1 < nk) load_tiles((kt + 1) * GBK);   // global loads fly under the MFMAs below
-#pragma unroll 4
-    for (int kk = 0; kk < GBK; kk += 2) {
-      float a[WM], b[WN];
+    // LDS operand reads are software-pipelined by hand: batch i+1 (PB K-steps) is read before the MFMAs of batch i issue.  Left to
+    // the compiler every MFMA waited on the ds_read issued just before it (~120 cycles of LDS latency per 64-cycle MFMA: measured
+    // 2.1x the MFMA bound per K-tile).
+    constexpr int NS = GBK / 2, PB = 4;
+    float fa[2][PB][WM], fb[2][PB][WN];
+    auto lds_batch = [&](int buf, int s0) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = As[a_off + i * 32 * GSTR + kk];
+      for (int u = 0; u < PB; ++u) {
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = Bs[b_off + j * 32 * GSTR + kk];
+        for (int i = 0; i < WM; ++i) fa[buf][u][i] = As[a_off + i * 32 * GSTR + 2 * (s0 + u)];
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+        for (int j = 0; j < WN; ++j) fb[buf][u][j] = Bs[b_off + j * 32 * GSTR + 2 * (s0 + u)];
+      }
+    };
+    lds_batch(0, 0);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    for (int s0 = 0; s0 < NS; s0 += PB) {
+      const int cur = (s0 / PB) & 1;
+      if (s0 + PB < NS) lds_batch(cur ^ 1, s0 + PB);
+      __builtin_amdgcn_sched_barrier(0);       // keep the reads of the next batch ahead of this batch's MFMAs
+#pragma unroll
+      for (int u = 0; u < PB; ++u)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u][i], fb[cur][u][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // epilogue: lane owns column n = ..+(lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -254,7 +295,7 @@ __global__ __launch_bounds__(256) void noise_mod1(float* __restrict__ x, const f
 
 const char* codec_conv_gemm_check(const ConvGemmArgs& g) {
   if (g.M <= 0 || g.N <= 0 || g.Cin <= 0 || g.taps <= 0) return "conv_gemm: bad shape";
-  if (g.Cin % GBK) return "conv_gemm: Cin must be a multiple of 32";
+  if (g.Cin % 32) return "conv_gemm: Cin must be a multiple of 32";
   if (g.ldx % 4 || ((uintptr_t)g.X & 15) || ((uintptr_t)g.W & 15)) return "conv_gemm: X rows / W must be 16-byte aligned";
   if (g.noise && !g.R) return "conv_gemm: noise modulation needs the residual input";
   if ((int64_t)g.M * g.x_row_mul + (int64_t)g.taps * g.dil > 0x7fffffffLL) return "conv_gemm: row index exceeds 31 bits";
@@ -266,13 +307,15 @@ int codec_conv_gemm_launch(const ConvGemmArgs& g, int phases, hipStream_t s) {
   const int64_t big_blocks = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * phases;
   if (big_blocks < 384) {
     dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, phases);
-    hipLaunchKernelGGL((conv_gemm_f32<1, 1>), grid, dim3(256), 0, s, g);
+    // at most ~1 workgroup per CU: nothing else hides the global-load latency of a stage, so stages are 4 chunks deep
+    if ((int64_t)grid.x * grid.y * grid.z <= 320 && g.taps * g.Cin >= 256) hipLaunchKernelGGL((conv_gemm_f32<1, 1, 4>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((conv_gemm_f32<1, 1, 1>), grid, dim3(256), 0, s, g);
   } else if (g.N > 64) {
     dim3 grid((g.M + 127) / 128, (g.N + 127) / 128, phases);
-    hipLaunchKernelGGL((conv_gemm_f32<2, 2>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((conv_gemm_f32<2, 2, 1>), grid, dim3(256), 0, s, g);
   } else {
     dim3 grid((g.M + 127) / 128, (g.N + 63) / 64, phases);
-    hipLaunchKernelGGL((conv_gemm_f32<2, 1>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((conv_gemm_f32<2, 1, 1>), grid, dim3(256), 0, s, g);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -35,3 +35,18 @@ extern "C" int mia_op_linear(mia_ctx* ctx, const void* x, int64_t lda, const voi
   }
   return MIA_OK;
 }
+
+// fp32 Conv1d / Linear on the exact-fp32 matrix cores (device pointers only): y[t][n] = act(b[n] + sum_{k,c} x[t*stride + k*dil - pad][c] w[n][k][c]) (+ r)
+#include "codec.h"
+extern "C" int mia_op_conv1d_f32(mia_ctx* ctx, const float* x, int64_t ldx, int T_in, const float* w, const float* bias, const float* r, float* y,
+                                 int64_t ldy, int T_out, int N, int Cin, int taps, int stride, int dil, int pad, int act) {
+  if (!ctx) return MIA_ERR_INVALID_ARGUMENT;
+  MIA_CHECK_ARG(ctx, x && w && y && T_in > 0 && T_out > 0 && N > 0 && taps > 0 && stride > 0 && dil > 0, "op_conv1d_f32: bad argument");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  ConvGemmArgs g;
+  g.X = x; g.ldx = ldx; g.T_in = T_in; g.W = w; g.bias = bias; g.Y = y; g.ldy = ldy; g.T_out = T_out; g.R = r; g.ldr = ldy;
+  g.M = T_out; g.N = N; g.Cin = Cin; g.taps = taps; g.dil = dil; g.pad = pad; g.x_row_mul = stride; g.gelu = act;
+  if (const char* e = codec_conv_gemm_check(g)) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
+  if (codec_conv_gemm_launch(g, 1, ctx->stream)) return mia_fail(ctx, MIA_ERR_DEVICE, "op_conv1d_f32: launch failed");
+  return MIA_OK;
+}
