@@ -12,8 +12,6 @@
 // accumulator registers are, in order, the B operand of O^T += V^T P^T (the A operand reads V rows in the matching key order).
 // K / P / V tiles of 32 keys are staged HBM -> registers -> LDS with row strides (66 | 130, 72 floats) that make every
 // fragment read bank-conflict free.
-#include <cstdlib>
-
 #include "mia_device.h"
 #include "ops.h"
 
@@ -63,14 +61,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
 
   // ---- staging: 2 tiles x 32 keys x 64 floats = 1024 float4 per source, 4 per thread: thread -> (tile = tid >> 7, row pair, 16-B column)
   const int s_tile = tid >> 7, s_row = (tid & 127) >> 4, s_c4 = (tid & 15) * 4;      // rows s_row + 8 j, j = 0..3
-  float4 rk[4], rp[4], rv[4];
+  f32x4 rk[4], rp[4], rv[4];       // native vectors: HIP's float4 struct copies were lowered to memcpy through a scratch array
   auto load_regs = [&](int key0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int key = key0 + 32 * s_tile + s_row + 8 * j; key = key < a.T ? key : a.T - 1;
-      rk[j] = *reinterpret_cast<const float4*>(K + (int64_t)key * a.ldk + s_c4);
-      rv[j] = *reinterpret_cast<const float4*>(V + (int64_t)key * a.ldv + s_c4);
-      if (POS) rp[j] = *reinterpret_cast<const float4*>(P + (int64_t)key * a.ldp + s_c4);
+      rk[j] = *reinterpret_cast<const f32x4*>(K + (int64_t)key * a.ldk + s_c4);
+      rv[j] = *reinterpret_cast<const f32x4*>(V + (int64_t)key * a.ldv + s_c4);
+      if (POS) rp[j] = *reinterpret_cast<const f32x4*>(P + (int64_t)key * a.ldp + s_c4);
     }
   };
   auto write_lds = [&]() {
@@ -78,13 +76,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     for (int j = 0; j < 4; ++j) {
       const int row = s_row + 8 * j;
       float* kd = Ks[s_tile] + row * SK + s_c4;              // rows are 8-byte aligned only
-      *reinterpret_cast<float2*>(kd) = make_float2(rk[j].x, rk[j].y);
-      *reinterpret_cast<float2*>(kd + 2) = make_float2(rk[j].z, rk[j].w);
+      *reinterpret_cast<float2*>(kd) = make_float2(rk[j][0], rk[j][1]);
+      *reinterpret_cast<float2*>(kd + 2) = make_float2(rk[j][2], rk[j][3]);
       if (POS) {
-        *reinterpret_cast<float2*>(kd + 64) = make_float2(rp[j].x, rp[j].y);
-        *reinterpret_cast<float2*>(kd + 66) = make_float2(rp[j].z, rp[j].w);
+        *reinterpret_cast<float2*>(kd + 64) = make_float2(rp[j][0], rp[j][1]);
+        *reinterpret_cast<float2*>(kd + 66) = make_float2(rp[j][2], rp[j][3]);
       }
-      *reinterpret_cast<float4*>(Vs[s_tile] + row * SV + s_c4) = rv[j];
+      *reinterpret_cast<f32x4*>(Vs[s_tile] + row * SV + s_c4) = rv[j];
     }
   };
 
@@ -100,10 +98,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
   for (int kp = 0; kp < npairs; ++kp) {
     const int key0 = kp * 64 + 32 * kvh;          // this wave's tile
     __syncthreads();                              // previous tiles fully consumed
-    if (!(a.dbg & 8) || kp == 0) write_lds();
+    write_lds();
     __syncthreads();
-    if (kp + 1 < npairs && !(a.dbg & 4)) load_regs((kp + 1) * 64);
-    if (key0 >= a.T) continue;                    // odd tail tile absent (wave-uniform)
+    if (kp + 1 < npairs) load_regs((kp + 1) * 64);
+    if (key0 < a.T) {                             // (the odd tail tile may be absent: wave-uniform)
 
     // ---- S^T = K Q^T
     f32x16 acc_s;
@@ -118,7 +116,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) kf[0][u] = kp_[2 * u];
 #pragma unroll
-      for (int bq = 0; bq < ((a.dbg & 1) ? 1 : NB); ++bq) {
+      for (int bq = 0; bq < NB; ++bq) {
         const int cur = bq & 1;
         if (bq + 1 < NB) {
 #pragma unroll
@@ -131,14 +129,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
       }
     }
 
-    // ---- online softmax (base 2): lane = one query, registers = keys (r&3) + 8 (r>>2) + 4 lh
+    // ---- online softmax (base 2): lane = one query, registers = keys (r&3) + 8 (r>>2) + 4 lh.  The probabilities go to their own
+    // scalar array: writing elements back into the MFMA result vector made the compiler round-trip it through scratch memory.
+    float pr[16];
     float mloc = -INFINITY;
     const bool tail = key0 + 32 > a.T;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float sv = acc_s[r];
       if (tail && key0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.T) sv = -INFINITY;
-      acc_s[r] = sv;
+      pr[r] = sv;
       mloc = fmaxf(mloc, sv);
     }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
@@ -148,9 +148,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     float lsum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(acc_s[r] - m_new);
-      acc_s[r] = p;
-      lsum += p;
+      pr[r] = __builtin_amdgcn_exp2f(pr[r] - m_new);
+      lsum += pr[r];
     }
     l_run = l_run * alpha + lsum;
 #pragma unroll
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) { vf[0][u][0] = vbase[u * SV]; vf[0][u][1] = vbase[u * SV + 32]; }
 #pragma unroll
-      for (int bq = 0; bq < ((a.dbg & 2) ? 1 : 4); ++bq) {       // batch bq = steps j = 4 bq .. 4 bq + 3 = key rows 8 bq + (0..3) + 4 lh
+      for (int bq = 0; bq < 4; ++bq) {       // batch bq = steps j = 4 bq .. 4 bq + 3 = key rows 8 bq + (0..3) + 4 lh
         const int cur = bq & 1;
         if (bq + 1 < 4) {
 #pragma unroll
@@ -174,11 +173,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][u][0], acc_s[4 * bq + u], acc_o[0], 0, 0, 0);
-          acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][u][1], acc_s[4 * bq + u], acc_o[1], 0, 0, 0);
+          acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][u][0], pr[4 * bq + u], acc_o[0], 0, 0, 0);
+          acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][u][1], pr[4 * bq + u], acc_o[1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
     }
   }
 
@@ -227,10 +227,7 @@ const char* mia_attn_f32_check(const AttnF32Args& a) {
   return nullptr;
 }
 
-int mia_attn_f32_launch(const AttnF32Args& a_in, hipStream_t s) {
-  AttnF32Args a = a_in;
-  static const char* dbg_env = getenv("MIA_ATTN_DBG");
-  if (dbg_env) a.dbg = atoi(dbg_env);
+int mia_attn_f32_launch(const AttnF32Args& a, hipStream_t s) {
   dim3 grid(((a.T + 63) / 64) * a.H * a.B), block(256);
   if (a.p) hipLaunchKernelGGL(attn_f32_kernel<true>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(attn_f32_kernel<false>, grid, block, 0, s, a);

@@ -25,7 +25,6 @@ struct AttnF32Args {
   float* out = nullptr; int64_t ldo = 0;
   int B = 1, T = 0, H = 0;
   float scale = 0.125f;
-  int dbg = 0;   // diagnostic only (MIA_ATTN_DBG): skip parts of the kernel to attribute time
 };
 const char* mia_attn_f32_check(const AttnF32Args& a);
 int mia_attn_f32_launch(const AttnF32Args& a, hipStream_t s);
