@@ -112,6 +112,13 @@ int mia_op_linear(mia_ctx* ctx, const void* x, int64_t lda, const void* w, const
 int mia_op_conv1d_f32(mia_ctx* ctx, const float* x, int64_t ldx, int T_in, const float* w, const float* bias, const float* r, float* y,
                       int64_t ldy, int T_out, int N, int Cin, int taps, int stride, int dil, int pad, int act);
 
+/* MLX affine de-quantisation of a checkpoint tensor at load time (the reference's default checkpoints are 4-bit, group 64:
+ * STT/Whisper/WhisperModel.swift:189-196, TTS/Orpheus/TTSEngine/OrpheusWeightLoader.swift:28-60):
+ *   out[r][c] = scales[r][c / group] * code[r][c] + biases[r][c / group],  code c of row r = bits [(c % (32/bits)) * bits, ...) of
+ *   wq[r][c / (32/bits)] (uint32, little end first).  bits 4 | 8; scales / biases in scale_dtype; out in out_dtype (MIA_F32 | F16 | BF16). */
+int mia_dequant_affine(mia_ctx* ctx, const uint32_t* wq, const void* scales, const void* biases, int64_t rows, int64_t cols,
+                       int group_size, int bits, int scale_dtype, void* out, int out_dtype, int mem);
+
 /* ---- Whisper ---------------------------------------------------------------------------------- */
 /* Model dimensions == ModelDimensions (STT/Whisper/Config/WhisperConfig.swift:9-86), read by the caller
  * from config.json. */
