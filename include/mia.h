@@ -203,6 +203,19 @@ int mia_whisper_transcribe_windows(mia_whisper* w, const float* pcm, const int64
                                    const mia_decode_opts* opts, int32_t* tokens, int32_t* n_tokens, float* avg_logprob,
                                    float* no_speech_prob, int mem);
 
+/* Word-timestamp alignment: the tensor half of findAlignment (STT/Whisper/WhisperTiming.swift:558-748; model.forwardWithCrossQK,
+ * STT/Whisper/WhisperModel.swift:95-99).  For every clip of the last encode: a teacher-forced decoder pass over
+ * tokens[b][0..n_tokens[b]) = [sot sequence, no_timestamps, text tokens, eot] keeps the pre-softmax cross-attention scores of the
+ * alignment heads (heads int32 [n_heads][2] = (layer, head), the model's alignment_heads); on the device: softmax over the first
+ * num_frames[b] / 2 frames, standardisation over tokens, width-7 median filter (reflect), mean over heads; on the host like the
+ * reference: DTW over rows [row_start, n_tokens[b] - 1) (row_start = index of no_timestamps) of the negated matrix.
+ *   token_probs [B][stride]: P(tokens[p + 1]) under softmax(logits[p][0:eot]);  text_idx / time_idx [B][path_cap] + path_len [B]: the
+ *   DTW path (row index relative to row_start, frame index);  matrix (nullable) [B][stride][n_audio_ctx]: the filtered, head-averaged
+ *   weights.  All host pointers.  Word splitting and the jump-time arithmetic (:735-820) stay with the caller (tokenizer text). */
+int mia_whisper_align(mia_whisper* w, const int32_t* tokens, int stride, const int32_t* n_tokens, const int32_t* heads, int n_heads,
+                      const int32_t* num_frames, int row_start, int eot, float* token_probs, int32_t* text_idx, int32_t* time_idx,
+                      int32_t* path_len, int path_cap, float* matrix);
+
 /* ---- neural codec decoders (fp32, like the reference) ------------------------------------------ */
 /* SNACConfig (TTS/Orpheus/SNAC/SNACConfig.swift:9-94); tensors use the checkpoint key schema the reference loads
  * (decoder.model.layers.N..., quantizer.quantizers.i.{codebook.weight,out_proj.{weight_g,weight_v,bias}};

@@ -277,7 +277,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
                                                      const uint16_t* __restrict__ vc, uint16_t* __restrict__ out,
                                                      const int32_t* __restrict__ pos_arr, int fixed_keys, int cap_keys, int H,
-                                                     float scale) {
+                                                     float scale, float* __restrict__ qk_out, const int32_t* __restrict__ head_slot,
+                                                     int n_slots, int qk_ctx) {
   __shared__ float sc[DEC_MAX_KEYS];
   __shared__ float red[4][64];
   __shared__ float red2[8];
@@ -315,6 +316,11 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
     }
   }
   __syncthreads();
+  // word-timestamp alignment (WhisperTiming.swift:605-640): keep the pre-softmax scores of the alignment heads, row = decoder position
+  if (qk_out && head_slot[h] >= 0) {
+    float* dst = qk_out + (((int64_t)b * n_slots + head_slot[h]) * qk_ctx + pos_arr[b]) * nk;
+    for (int i = tid; i < nk; i += 256) dst[i] = sc[i];
+  }
   // ---- softmax over sc[0..nk)
   float m = -INFINITY;
   for (int i = tid; i < nk; i += 256) m = fmaxf(m, sc[i]);
@@ -660,13 +666,13 @@ int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) 
 int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s) { return skinny_gemm_launch(a, mode, w->dtype, s); }
 
 int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const void* vc, void* out, int fixed_keys, int cap_keys,
-                         hipStream_t s) {
+                         hipStream_t s, float* qk_out, const int32_t* head_slot, int n_slots, int qk_ctx) {
   if (cap_keys > DEC_MAX_KEYS) return -1;
   dim3 grid(w->dims.n_text_head, w->cur_B), block(256);
   if (w->dtype == MIA_F16)
-    hipLaunchKernelGGL(dec_attention<F16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->clip.pos, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f);
+    hipLaunchKernelGGL(dec_attention<F16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->clip.pos, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f, qk_out, head_slot, n_slots, qk_ctx);
   else
-    hipLaunchKernelGGL(dec_attention<BF16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->clip.pos, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f);
+    hipLaunchKernelGGL(dec_attention<BF16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->clip.pos, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f, qk_out, head_slot, n_slots, qk_ctx);
   return 0;
 }
 

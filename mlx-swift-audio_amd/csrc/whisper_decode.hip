@@ -5,7 +5,9 @@
 // Prefill note: the reference feeds the n_initial forced tokens in one causal pass; here they are fed one position
 // per step through the same graph (mathematically identical: causal attention only sees earlier positions).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #include "decode.h"
 
@@ -16,8 +18,46 @@ int pick_split(int K, int want) {  // largest S <= want with K % (32*S) == 0
   return 1;
 }
 
+// teacher-forced alignment pass (mia_whisper_align): cross-attention scores of the alignment heads are kept, and the decode head is
+// replaced by "probability of the next given token + advance"
+struct AlignHook {
+  float* qk = nullptr;                    // [B][n_slots][n_ctx][T]
+  const int32_t* head_slot = nullptr;     // device [L][H]: slot or -1
+  int n_slots = 0;
+  const int32_t* n_tok = nullptr;         // device [B]
+  float* probs = nullptr;                 // device [B][n_ctx]
+  int eot = 0;
+};
+
+__global__ __launch_bounds__(256) void align_token_prob(const float* __restrict__ logits, const int32_t* __restrict__ tokens, int32_t* __restrict__ pos_arr,
+                                                        const int32_t* __restrict__ n_tok, float* __restrict__ probs, int V, int n_ctx, int eot) {
+  __shared__ float red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pos = pos_arr[b];
+  if (pos + 1 < n_tok[b]) {     // logits at `pos` predict tokens[pos + 1]: softmax over [0, eot)   (WhisperTiming.swift:600-611)
+    const float* lg = logits + (int64_t)b * V;
+    float m = -INFINITY;
+    for (int i = tid; i < eot; i += 256) m = fmaxf(m, lg[i]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < eot; i += 256) sum += expf(lg[i] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    if (tid == 0) {
+      const int t = tokens[(int64_t)b * n_ctx + pos + 1];
+      probs[(int64_t)b * n_ctx + pos] = t < eot ? expf(lg[t] - m) / sum : 0.f;
+      pos_arr[b] = pos + 1;
+    }
+  }
+}
+
 // enqueue one decoder step (consumes the token at st->pos, produces the token at st->pos + 1)
-int enqueue_step(mia_whisper* w, const DecodeParams& p) {
+int enqueue_step(mia_whisper* w, const DecodeParams& p, const AlignHook* hook = nullptr) {
   hipStream_t s = w->ctx->stream;
   const int B = w->cur_B, D = p.D, H = p.H, C = p.n_ctx, T = w->dims.n_audio_ctx;
   const uint16_t* dh = (const uint16_t*)w->dh;
@@ -41,7 +81,8 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p) {
     dec_launch_reduce_ln(w, S_d, b.out.b, b.cross_ln, s);
     // cross attention (K/V primed by the encode call)
     if (skinny(dh, D, b.cq, true, w->dq, D, 1, MIA_ACT_NONE, SK_OUT16)) return -1;
-    if (dec_launch_attention(w, w->dq, xk, xv, w->da, T, T, s)) return -1;
+    if (dec_launch_attention(w, w->dq, xk, xv, w->da, T, T, s, hook ? hook->qk : nullptr, hook ? hook->head_slot + (size_t)l * H : nullptr,
+                             hook ? hook->n_slots : 0, C)) return -1;
     if (skinny((const uint16_t*)w->da, D, b.cout, false, w->partial, 0, S_d, MIA_ACT_NONE, SK_PARTIAL)) return -1;
     dec_launch_reduce_ln(w, S_d, b.cout.b, b.mlp_ln, s);
     // MLP
@@ -52,6 +93,10 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p) {
   {  // logits = ln(x) . E^T (tied embedding, TextDecoder.swift:93)
     LinearW e; e.w = w->tok_emb; e.N = p.V; e.K = D;
     if (skinny(dh, D, e, false, w->logits, p.V, 1, MIA_ACT_NONE, SK_OUTF32)) return -1;
+  }
+  if (hook) {
+    hipLaunchKernelGGL(align_token_prob, dim3(B), dim3(256), 0, s, w->logits, w->tokens, w->clip.pos, hook->n_tok, hook->probs, p.V, C, hook->eot);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
   }
   if (dec_launch_head(w, w->last_ts, p, s)) return -1;
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -179,6 +224,189 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
   if (avg_logprob) MIA_HIP(ctx, hipMemcpyAsync(avg_logprob, w->out_avg, (size_t)B * 4, kind, s));
   if (no_speech_prob) MIA_HIP(ctx, hipMemcpyAsync(no_speech_prob, w->no_speech, (size_t)B * 4, kind, s));
   if (mem == MIA_MEM_HOST) MIA_HIP(ctx, hipStreamSynchronize(s));
+  return MIA_OK;
+}
+
+// ---- word-timestamp alignment -------------------------------------------------------------------------------
+namespace {
+
+// softmax over the first F_b frames of every (clip, head, token) row, in place   (WhisperTiming.swift:658)
+__global__ __launch_bounds__(256) void align_softmax_rows(float* __restrict__ qk, const int32_t* __restrict__ n_tok, const int32_t* __restrict__ n_fr,
+                                                          int n_slots, int n_ctx, int T) {
+  __shared__ float red[8];
+  const int tok = blockIdx.x, slot = blockIdx.y, b = blockIdx.z;
+  if (tok >= n_tok[b]) return;
+  const int F = n_fr[b];
+  float* row = qk + (((int64_t)b * n_slots + slot) * n_ctx + tok) * T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -INFINITY;
+  for (int i = tid; i < F; i += 256) m = fmaxf(m, row[i]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = tid; i < F; i += 256) sum += expf(row[i] - m);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = (red[4] + red[5]) + (red[6] + red[7]);
+  for (int i = tid; i < F; i += 256) row[i] = expf(row[i] - m) / sum;
+}
+
+// (w - mean_tokens) / sqrt(var_tokens + 1e-8) per (clip, head, frame) column, population variance   (:663-666)
+__global__ __launch_bounds__(256) void align_standardize(float* __restrict__ qk, const int32_t* __restrict__ n_tok, const int32_t* __restrict__ n_fr,
+                                                         int n_slots, int n_ctx, int T) {
+  const int f = blockIdx.x * 256 + threadIdx.x, slot = blockIdx.y, b = blockIdx.z;
+  if (f >= n_fr[b]) return;
+  const int n = n_tok[b];
+  float* col = qk + ((int64_t)b * n_slots + slot) * n_ctx * T + f;
+  float s = 0.f;
+  for (int t = 0; t < n; ++t) s += col[(int64_t)t * T];
+  const float mean = s / (float)n;
+  float q = 0.f;
+  for (int t = 0; t < n; ++t) { const float d = col[(int64_t)t * T] - mean; q += d * d; }
+  const float inv = 1.0f / sqrtf(q / (float)n + 1e-8f);
+  for (int t = 0; t < n; ++t) col[(int64_t)t * T] = (col[(int64_t)t * T] - mean) * inv;
+}
+
+__device__ __forceinline__ void cswap(float& a, float& b) { const float lo = fminf(a, b), hi = fmaxf(a, b); a = lo; b = hi; }
+__device__ __forceinline__ float median7(float v0, float v1, float v2, float v3, float v4, float v5, float v6) {
+  // 7-input sorting network (16 compare-exchanges), element 3 is the median
+  cswap(v0, v6); cswap(v2, v3); cswap(v4, v5);
+  cswap(v0, v2); cswap(v1, v4); cswap(v3, v6);
+  cswap(v0, v1); cswap(v2, v5); cswap(v3, v4);
+  cswap(v1, v2); cswap(v4, v6);
+  cswap(v2, v3); cswap(v4, v5);
+  cswap(v1, v2); cswap(v3, v4); cswap(v5, v6);
+  return v3;
+}
+
+// width-7 median along frames with reflect padding, mean over heads, negated (DTW cost)   (:683-722, medianFilterAttention :191-253)
+__global__ __launch_bounds__(256) void align_median_mean(const float* __restrict__ qk, const int32_t* __restrict__ n_tok, const int32_t* __restrict__ n_fr,
+                                                         int n_slots, int n_ctx, int T, float* __restrict__ cost) {
+  const int f = blockIdx.x * 256 + threadIdx.x, tok = blockIdx.y, b = blockIdx.z;
+  const int F = n_fr[b];
+  if (f >= F || tok >= n_tok[b]) return;
+  float acc = 0.f;
+  for (int sl = 0; sl < n_slots; ++sl) {
+    const float* row = qk + (((int64_t)b * n_slots + sl) * n_ctx + tok) * T;
+    float v[7];
+#pragma unroll
+    for (int d = -3; d <= 3; ++d) {
+      int i = f + d;
+      if (i < 0) i = -i;
+      if (i >= F) i = 2 * F - i - 2;
+      i = i < 0 ? 0 : (i > F - 1 ? F - 1 : i);
+      v[d + 3] = row[i];
+    }
+    acc += median7(v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
+  }
+  cost[((int64_t)b * n_ctx + tok) * T + f] = -(acc / (float)n_slots);
+}
+
+// dtw + backtrace (WhisperTiming.swift:46-130), host code like the reference's; cost is [N][ld] with M valid columns
+void dtw_host(const float* cost, int N, int M, int64_t ld, std::vector<int32_t>& ti, std::vector<int32_t>& tj) {
+  const int R = N + 1, Cc = M + 1;
+  std::vector<float> acc((size_t)R * Cc, INFINITY);
+  std::vector<int8_t> tr((size_t)R * Cc, -1);
+  acc[0] = 0.f;
+  for (int j = 1; j <= M; ++j)
+    for (int i = 1; i <= N; ++i) {
+      const float c0 = acc[(size_t)(i - 1) * Cc + j - 1], c1 = acc[(size_t)(i - 1) * Cc + j], c2 = acc[(size_t)i * Cc + j - 1];
+      float c; int8_t t;
+      if (c0 < c1 && c0 < c2) { c = c0; t = 0; } else if (c1 < c0 && c1 < c2) { c = c1; t = 1; } else { c = c2; t = 2; }
+      acc[(size_t)i * Cc + j] = cost[(int64_t)(i - 1) * ld + (j - 1)] + c;
+      tr[(size_t)i * Cc + j] = t;
+    }
+  for (int j = 0; j < Cc; ++j) tr[j] = 2;
+  for (int i = 0; i < R; ++i) tr[(size_t)i * Cc] = 1;
+  int i = N, j = M;
+  ti.clear(); tj.clear();
+  while (i > 0 || j > 0) {
+    ti.push_back(i - 1); tj.push_back(j - 1);
+    const int8_t t = tr[(size_t)i * Cc + j];
+    if (t == 0) { --i; --j; } else if (t == 1) --i; else if (t == 2) --j; else { if (i > 0) --i; if (j > 0) --j; }
+  }
+  std::reverse(ti.begin(), ti.end()); std::reverse(tj.begin(), tj.end());
+}
+
+}  // namespace
+
+extern "C" int mia_whisper_align(mia_whisper* w, const int32_t* tokens, int stride, const int32_t* n_tokens, const int32_t* heads, int n_heads,
+                                 const int32_t* num_frames, int row_start, int eot, float* token_probs, int32_t* text_idx, int32_t* time_idx,
+                                 int32_t* path_len, int path_cap, float* matrix) {
+  if (!w) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = w->ctx;
+  const mia_whisper_dims& d = w->dims;
+  const int B = w->cur_B, C = d.n_text_ctx, T = d.n_audio_ctx, H = d.n_text_head, L = d.n_text_layer;
+  MIA_CHECK_ARG(ctx, B > 0, "align: no audio features (call mia_whisper_encode first)");
+  MIA_CHECK_ARG(ctx, tokens && n_tokens && heads && num_frames && token_probs && text_idx && time_idx && path_len, "align: null argument");
+  MIA_CHECK_ARG(ctx, n_heads > 0 && n_heads <= 64 && stride > 0 && stride <= C && row_start >= 0 && eot > 0 && eot <= d.n_vocab && path_cap > 0, "align: bad sizes");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  std::vector<int32_t> slot((size_t)L * H, -1), ntok(B), nfr(B), init((size_t)B * C, 0);
+  for (int i = 0; i < n_heads; ++i) {
+    const int l = heads[2 * i], h = heads[2 * i + 1];
+    MIA_CHECK_ARG(ctx, l >= 0 && l < L && h >= 0 && h < H, "align: alignment head (%d, %d) out of range", l, h);
+    slot[(size_t)l * H + h] = i;
+  }
+  int max_tok = 0;
+  for (int b = 0; b < B; ++b) {
+    ntok[b] = n_tokens[b];
+    MIA_CHECK_ARG(ctx, ntok[b] >= 2 && ntok[b] <= stride && row_start < ntok[b] - 1, "align: clip %d: token count %d out of range", b, ntok[b]);
+    nfr[b] = num_frames[b] / 2;                               // stride-2 convolution (WhisperTiming.swift:622)
+    MIA_CHECK_ARG(ctx, nfr[b] >= 2 && nfr[b] <= T, "align: clip %d: frame count out of range", b);
+    for (int i = 0; i < ntok[b]; ++i) {
+      const int32_t t = tokens[(size_t)b * stride + i];
+      MIA_CHECK_ARG(ctx, t >= 0 && t < d.n_vocab, "align: token out of vocabulary");
+      init[(size_t)b * C + i] = t;
+    }
+    max_tok = std::max(max_tok, ntok[b]);
+  }
+  // device scratch: qk [B][n_heads][C][T] | cost [B][C][T] | probs [B][C] | slot [L][H] | ntok [B] | nfr [B]
+  const size_t n_qk = (size_t)B * n_heads * C * T, n_cost = (size_t)B * C * T;
+  auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+  const size_t floats = al(n_qk) + al(n_cost) + al((size_t)B * C) + al((size_t)L * H) + 2 * al(B);
+  float* ws = (float*)mia_workspace(ctx, floats * 4);
+  if (!ws) return MIA_ERR_OUT_OF_MEMORY;
+  float* d_qk = ws; float* d_cost = d_qk + al(n_qk); float* d_probs = d_cost + al(n_cost);
+  int32_t* d_slot = (int32_t*)(d_probs + al((size_t)B * C)); int32_t* d_ntok = d_slot + al((size_t)L * H); int32_t* d_nfr = d_ntok + al(B);
+  MIA_HIP(ctx, hipMemcpyAsync(w->tokens, init.data(), init.size() * 4, hipMemcpyHostToDevice, s));
+  MIA_HIP(ctx, hipMemcpyAsync(d_slot, slot.data(), slot.size() * 4, hipMemcpyHostToDevice, s));
+  MIA_HIP(ctx, hipMemcpyAsync(d_ntok, ntok.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  MIA_HIP(ctx, hipMemcpyAsync(d_nfr, nfr.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  MIA_HIP(ctx, hipMemsetAsync(w->clip.pos, 0, (size_t)B * 4, s));
+  MIA_HIP(ctx, hipMemsetAsync(d_probs, 0, (size_t)B * C * 4, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));       // host vectors above go out of use
+
+  DecodeParams p{};
+  p.B = B; p.V = d.n_vocab; p.D = d.n_text_state; p.H = H; p.L = L; p.n_ctx = C;
+  AlignHook hook; hook.qk = d_qk; hook.head_slot = d_slot; hook.n_slots = n_heads; hook.n_tok = d_ntok; hook.probs = d_probs; hook.eot = eot;
+  // teacher-forced pass, one position per step (clips that have consumed their last token idle at it)
+  for (int step = 0; step < max_tok; ++step)
+    if (enqueue_step(w, p, &hook) != 0) return mia_fail(ctx, MIA_ERR_DEVICE, "align: step launch failed");
+  hipLaunchKernelGGL(align_softmax_rows, dim3(max_tok, n_heads, B), dim3(256), 0, s, d_qk, d_ntok, d_nfr, n_heads, C, T);
+  hipLaunchKernelGGL(align_standardize, dim3((T + 255) / 256, n_heads, B), dim3(256), 0, s, d_qk, d_ntok, d_nfr, n_heads, C, T);
+  hipLaunchKernelGGL(align_median_mean, dim3((T + 255) / 256, max_tok, B), dim3(256), 0, s, d_qk, d_ntok, d_nfr, n_heads, C, T, d_cost);
+  MIA_HIP(ctx, hipGetLastError());
+  std::vector<float> cost(n_cost);
+  MIA_HIP(ctx, hipMemcpyAsync(cost.data(), d_cost, n_cost * 4, hipMemcpyDeviceToHost, s));
+  std::vector<float> probs((size_t)B * C);
+  MIA_HIP(ctx, hipMemcpyAsync(probs.data(), d_probs, probs.size() * 4, hipMemcpyDeviceToHost, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  std::vector<int32_t> ti, tj;
+  for (int b = 0; b < B; ++b) {
+    for (int i = 0; i < stride; ++i) token_probs[(size_t)b * stride + i] = i < C ? probs[(size_t)b * C + i] : 0.f;
+    const int N = ntok[b] - 1 - row_start;       // rows [row_start, n_tok - 1): no_timestamps + text tokens, eot excluded (:724-733)
+    dtw_host(cost.data() + ((size_t)b * C + row_start) * T, N, nfr[b], T, ti, tj);
+    if ((int)ti.size() > path_cap) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "align: path_cap %d too small (need %zu)", path_cap, ti.size());
+    path_len[b] = (int32_t)ti.size();
+    for (size_t i = 0; i < ti.size(); ++i) { text_idx[(size_t)b * path_cap + i] = ti[i]; time_idx[(size_t)b * path_cap + i] = tj[i]; }
+    if (matrix)
+      for (int t = 0; t < ntok[b]; ++t)
+        for (int f2 = 0; f2 < T; ++f2) matrix[((size_t)b * stride + t) * T + f2] = f2 < nfr[b] ? -cost[((size_t)b * C + t) * T + f2] : 0.f;
+  }
   return MIA_OK;
 }
 

@@ -152,7 +152,7 @@ class WhisperOracle:
         return _linear(wv, W[p + ".out.weight"], W[p + ".out.bias"]), (k, v), qk
 
     # ---- ResidualAttentionBlock.swift:51-95
-    def _block(self, p, x, n_head, xa=None, mask=None, kv_cache=None, offset=0):
+    def _block(self, p, x, n_head, xa=None, mask=None, kv_cache=None, offset=0, cross_qk_out=None):
         W = self.w
         self_kv = kv_cache[0] if kv_cache else None
         cross_kv = kv_cache[1] if kv_cache else None
@@ -161,8 +161,10 @@ class WhisperOracle:
         x = x + y
         new_cross = cross_kv
         if xa is not None:
-            y, new_cross, _ = self._attn(p + ".cross_attn", _layer_norm(x, W[p + ".cross_attn_ln.weight"], W[p + ".cross_attn_ln.bias"]),
-                                         n_head, xa=xa, kv_cache=cross_kv)
+            y, new_cross, cqk = self._attn(p + ".cross_attn", _layer_norm(x, W[p + ".cross_attn_ln.weight"], W[p + ".cross_attn_ln.bias"]),
+                                           n_head, xa=xa, kv_cache=cross_kv)
+            if cross_qk_out is not None:
+                cross_qk_out.append(cqk)
             x = x + y
         h = _layer_norm(x, W[p + ".mlp_ln.weight"], W[p + ".mlp_ln.bias"])
         x = x + _linear(_gelu(_linear(h, W[p + ".mlp1.weight"], W[p + ".mlp1.bias"])), W[p + ".mlp2.weight"], W[p + ".mlp2.bias"])
@@ -181,7 +183,7 @@ class WhisperOracle:
         return _layer_norm(x, W["encoder.ln_post.weight"], W["encoder.ln_post.bias"])
 
     # ---- TextDecoder.swift:53-96
-    def decode(self, tokens: list[int] | np.ndarray, xa: torch.Tensor, kv_cache=None):
+    def decode(self, tokens: list[int] | np.ndarray, xa: torch.Tensor, kv_cache=None, cross_qk_out=None):
         W, d = self.w, self.dims
         tok = torch.as_tensor(np.asarray(tokens, np.int64)).reshape(1, -1)
         offset = kv_cache[0][0][0].shape[1] if kv_cache is not None and kv_cache[0][0] is not None else 0
@@ -190,7 +192,7 @@ class WhisperOracle:
         new_cache = []
         for l in range(d.n_text_layer):
             x, c = self._block(f"decoder.blocks.{l}", x, d.n_text_head, xa=xa, mask=self.mask,
-                               kv_cache=kv_cache[l] if kv_cache is not None else None, offset=offset)
+                               kv_cache=kv_cache[l] if kv_cache is not None else None, offset=offset, cross_qk_out=cross_qk_out)
             new_cache.append(c)
         x = _layer_norm(x, W["decoder.ln.weight"], W["decoder.ln.bias"])
         return x @ W["decoder.token_embedding.weight"].t(), new_cache
@@ -331,3 +333,79 @@ def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: 
     if st.eot in gen:
         gen = gen[:gen.index(st.eot)]
     return DecodingResult(gen, avg, no_speech_prob, margins, init)
+
+
+# ---- word timestamps: WhisperTiming.swift (dtw :46-130, medianFilterAttention :191-253, findAlignment :558-748) ----------------------
+def dtw(cost: np.ndarray):
+    """cost [N, M] -> (text_indices, time_indices), tie rules of WhisperTiming.swift:70-78."""
+    N, M = cost.shape
+    acc = np.full((N + 1, M + 1), np.inf, np.float32)
+    trace = -np.ones((N + 1, M + 1), np.int8)
+    acc[0, 0] = 0
+    for j in range(1, M + 1):
+        for i in range(1, N + 1):
+            c0, c1, c2 = acc[i - 1, j - 1], acc[i - 1, j], acc[i, j - 1]
+            if c0 < c1 and c0 < c2:
+                c, t = c0, 0
+            elif c1 < c0 and c1 < c2:
+                c, t = c1, 1
+            else:
+                c, t = c2, 2
+            acc[i, j] = np.float32(cost[i - 1, j - 1]) + c
+            trace[i, j] = t
+    trace[0, :] = 2
+    trace[:, 0] = 1
+    i, j = N, M
+    out = []
+    while i > 0 or j > 0:
+        out.append((i - 1, j - 1))
+        t = trace[i, j]
+        if t == 0:
+            i, j = i - 1, j - 1
+        elif t == 1:
+            i -= 1
+        else:
+            j -= 1
+    out.reverse()
+    return [a for a, _ in out], [b for _, b in out]
+
+
+def median_filter7(w: np.ndarray) -> np.ndarray:
+    """width-7 median along the last axis with reflect padding (scipy.signal.medfilt-with-reflect, :227-247)."""
+    F = w.shape[-1]
+    idx = np.arange(F)[:, None] + np.arange(-3, 4)[None, :]
+    idx = np.where(idx < 0, -idx, idx)
+    idx = np.where(idx >= F, 2 * F - idx - 2, idx)
+    idx = np.clip(idx, 0, F - 1)
+    return np.median(w[..., idx], axis=-1).astype(np.float32)
+
+
+def alignment_matrix(model: "WhisperOracle", xa: torch.Tensor, tokens: list[int], heads: list[tuple[int, int]], num_frames: int, eot: int):
+    """findAlignment up to the DTW input: returns (matrix [n_tok, frames], token_probs [n_tok - 1])."""
+    qks: list = []
+    logits, _ = model.decode(tokens, xa, cross_qk_out=qks)
+    F = num_frames // 2
+    wts = torch.stack([qks[l][0, h] for l, h in heads])[:, :, :F]
+    wts = torch.softmax(wts, dim=-1)
+    mean = wts.mean(dim=-2, keepdim=True)
+    var = wts.var(dim=-2, keepdim=True, unbiased=False)
+    wts = ((wts - mean) / torch.sqrt(var + 1e-8)).numpy().astype(np.float32)
+    mat = median_filter7(wts).mean(axis=0)
+    lp = torch.softmax(logits[0, :, :eot], dim=-1).numpy()
+    probs = np.asarray([lp[p, tokens[p + 1]] if tokens[p + 1] < eot else 0.0 for p in range(len(tokens) - 1)], np.float32)
+    return mat, probs
+
+
+def word_times(text_idx, time_idx, word_groups, tokens_per_second: float = 50.0):
+    """jump / boundary arithmetic of findAlignment (:735-790): word_groups = token groups of the words + the eot group."""
+    boundaries = [0]
+    for g in word_groups[:-1]:
+        boundaries.append(boundaries[-1] + len(g))
+    jumps = [0] + [i for i in range(1, len(text_idx)) if text_idx[i] != text_idx[i - 1]]
+    jt = [time_idx[i] / tokens_per_second for i in jumps]
+    out = []
+    for i in range(len(word_groups) - 1):
+        s = jt[boundaries[i]] if boundaries[i] < len(jt) else (jt[-1] if jt else 0.0)
+        e = jt[boundaries[i + 1]] if boundaries[i + 1] < len(jt) else (jt[-1] if jt else s)
+        out.append((s, max(e, s)))
+    return out
