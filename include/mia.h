@@ -96,6 +96,12 @@ int mia_logmel_s3(mia_ctx* ctx, const float* pcm, const int64_t* offs, int B, in
 int64_t mia_mel_s3gen_frames(int64_t n_samples);
 int mia_mel_s3gen(mia_ctx* ctx, const float* pcm, int64_t n_samples, float* mel, int mem);
 
+/* Linear-interpolation resampler of the CosyVoice2 prompt path (resampleAudio -> linearInterpolate1d, TTS/CosyVoice2/CosyVoice2TTS.swift:733-744,
+ * TTS/CosyVoice2/HiFiGAN/CosyHiFTGenerator.swift:17-60; align_corners = false index rule, float32 arithmetic as in the reference).
+ * scale = to_rate / from_rate as float32; out holds mia_resample_linear_len(n_samples, scale) samples. */
+int64_t mia_resample_linear_len(int64_t n_samples, float scale);
+int mia_resample_linear(mia_ctx* ctx, const float* x, int64_t n_samples, float scale, float* out, int mem);
+
 /* ---- operator level -------------------------------------------------------------------------- */
 /* y = act(x W^T + b) + r : the dense contraction behind every MLXNN Linear on the path
  * (e.g. STT/Whisper/Layers/MultiHeadAttention.swift:40-58,134; ResidualAttentionBlock.swift:91).

@@ -105,3 +105,22 @@ def s3gen_mel_spectrogram(ctx: _lib.Context, y) -> np.ndarray:
     out = np.empty((80, frames), np.float32)
     ctx.check(lib.mia_mel_s3gen(ctx.h, a.ctypes.data, a.shape[0], out.ctypes.data, _lib.MEM_HOST))
     return out
+
+
+def resample_audio(ctx: _lib.Context, audio, from_rate: int, to_rate: int) -> np.ndarray:
+    """resampleAudio (TTS/CosyVoice2/CosyVoice2TTS.swift:733-744): plain linear interpolation, ratio in float32."""
+    import ctypes as C
+    a = np.ascontiguousarray(audio, np.float32).reshape(-1)
+    if from_rate == to_rate:
+        return a
+    lib = ctx.lib
+    if not getattr(lib, "_rs_declared", False):
+        lib.mia_resample_linear_len.restype = C.c_int64
+        lib.mia_resample_linear_len.argtypes = [C.c_int64, C.c_float]
+        lib.mia_resample_linear.restype = C.c_int
+        lib.mia_resample_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int]
+        lib._rs_declared = True
+    ratio = float(np.float32(to_rate) / np.float32(from_rate))
+    out = np.empty(int(lib.mia_resample_linear_len(a.shape[0], ratio)), np.float32)
+    ctx.check(lib.mia_resample_linear(ctx.h, a.ctypes.data, a.shape[0], ratio, out.ctypes.data, _lib.MEM_HOST))
+    return out

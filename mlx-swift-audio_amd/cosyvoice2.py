@@ -1,6 +1,6 @@
 """Host-side mirror of CosyVoice2Model (TTS/CosyVoice2/CosyVoice2Model.swift:28-208) and of the tensor part of
 prepareConditionals (TTS/CosyVoice2/CosyVoice2TTS.swift:370-430): generateTokens -> tokensToMel -> melToAudio, every stage on
-the gfx950 HIP layer.  Text tokenisation, resampling of the reference clip and the CAM++ speaker encoder stay with the caller
+the gfx950 HIP layer.  Text tokenisation and the CAM++ speaker encoder stay with the caller
 (CPU text code / one-off per speaker), so text arrives as token ids and the speaker as its 192-d embedding.
 Every random draw of the reference is an explicit argument: `uniforms` (RAS sampler), `z` (CFM noise), `noise` (HiFT source)."""
 from __future__ import annotations
@@ -24,11 +24,14 @@ class CosyVoice2Model:
         self.ctx, self.llm, self.flow, self.hifigan, self.s3 = ctx, llm, flow, hifigan, s3_tokenizer
 
     # ---- prepareConditionals, tensor part (CosyVoice2TTS.swift:383-423) -------------------------------------------------------------
-    def prepare_conditionals(self, ref_wav_16k: np.ndarray, ref_wav_24k: np.ndarray, speaker_embedding: np.ndarray, prompt_text=()):
+    def prepare_conditionals(self, ref_wav: np.ndarray, speaker_embedding: np.ndarray, prompt_text=()):
+        """ref_wav: 24 kHz mono reference clip (at most 30 s are used, CosyVoice2TTS.swift:375-380)."""
         from . import audio as A
         if self.s3 is None:
             raise ValueError("CosyVoice2Model was built without an S3 tokenizer")
-        mel128 = A.s3_log_mel_spectrogram(self.ctx, np.ascontiguousarray(ref_wav_16k, np.float32), 128)
+        ref_wav_24k = np.ascontiguousarray(ref_wav, np.float32)[:30 * 24000]
+        ref_wav_16k = A.resample_audio(self.ctx, ref_wav_24k, 24000, 16000)
+        mel128 = A.s3_log_mel_spectrogram(self.ctx, ref_wav_16k, 128)
         tk, nt = self.s3.quantize(mel128[None], np.asarray([mel128.shape[1]], np.int32))
         toks = np.asarray(tk[0][:int(nt[0])], np.int32)
         mel80 = A.s3gen_mel_spectrogram(self.ctx, ref_wav_24k).T                       # [frames, 80]

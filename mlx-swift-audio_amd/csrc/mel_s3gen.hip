@@ -151,3 +151,51 @@ extern "C" int mia_mel_s3gen(mia_ctx* ctx, const float* pcm, int64_t n_samples, 
   }
   return MIA_OK;
 }
+
+// ---- linear-interpolation resampler of the CosyVoice2 prompt path ---------------------------------------------------------------------------
+// Replaces resampleAudio -> linearInterpolate1d (TTS/CosyVoice2/CosyVoice2TTS.swift:733-744, TTS/CosyVoice2/HiFiGAN/CosyHiFTGenerator.swift:17-60):
+// new_T = int(float(T) * scale) (at least 1); src = (i + 0.5) * (float(T) / float(new_T)) - 0.5 clipped to [0, T - 1.001];
+// out = x[floor] * (1 - frac) + x[min(floor + 1, T - 1)] * frac -- every operation in float32 and unfused, like the reference.
+namespace {
+__global__ __launch_bounds__(256) void resample_linear_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t T, int64_t newT, float ratio,
+                                                              float clip_hi) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= newT) return;
+  float idx = __fsub_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), ratio), 0.5f);
+  idx = fminf(fmaxf(idx, 0.f), clip_hi);
+  const float lo = floorf(idx);
+  const int64_t ilo = (int64_t)lo, ihi = ilo + 1 < T - 1 ? ilo + 1 : T - 1;
+  const float wh = __fsub_rn(idx, lo), wl = __fsub_rn(1.0f, wh);
+  out[i] = __fadd_rn(__fmul_rn(x[ilo], wl), __fmul_rn(x[ihi], wh));
+}
+}  // namespace
+
+extern "C" int64_t mia_resample_linear_len(int64_t n_samples, float scale) {
+  const int64_t n = (int64_t)((float)n_samples * scale);
+  return n == 0 ? 1 : n;
+}
+
+extern "C" int mia_resample_linear(mia_ctx* ctx, const float* x, int64_t n_samples, float scale, float* out, int mem) {
+  if (!ctx) return MIA_ERR_INVALID_ARGUMENT;
+  MIA_CHECK_ARG(ctx, x && out && n_samples > 0 && n_samples < ((int64_t)1 << 24) && scale > 0.f && (mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE),
+                "resample_linear: bad argument (n_samples must stay below 2^24: the reference indexes in float32)");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t newT = mia_resample_linear_len(n_samples, scale);
+  hipStream_t s = ctx->stream;
+  const float* d_x = x; float* d_o = out;
+  if (mem == MIA_MEM_HOST) {
+    auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+    float* ws = (float*)mia_workspace(ctx, (al(n_samples) + al(newT)) * 4);
+    if (!ws) return MIA_ERR_OUT_OF_MEMORY;
+    MIA_HIP(ctx, hipMemcpyAsync(ws, x, (size_t)n_samples * 4, hipMemcpyHostToDevice, s));
+    d_x = ws; d_o = ws + al(n_samples);
+  }
+  hipLaunchKernelGGL(resample_linear_kernel, dim3((unsigned)((newT + 255) / 256)), dim3(256), 0, s, d_x, d_o, n_samples, newT,
+                     (float)n_samples / (float)newT, (float)n_samples - 1.001f);
+  MIA_HIP(ctx, hipGetLastError());
+  if (mem == MIA_MEM_HOST) {
+    MIA_HIP(ctx, hipMemcpyAsync(out, d_o, (size_t)newT * 4, hipMemcpyDeviceToHost, s));
+    MIA_HIP(ctx, hipStreamSynchronize(s));
+  }
+  return MIA_OK;
+}

@@ -32,12 +32,11 @@ def test_zero_shot_pipeline(ctx):
     s3 = HS.S3Tokenizer.load(ctx, scfg, S.s3_weights(scfg, 3))
     model = CV.CosyVoice2Model(ctx, llm, flow, hift, s3)
 
-    # ---- conditionals from a 2 s reference clip (the 24 kHz copy is an independent synthetic clip: resampling is the caller's)
-    ref16 = OL.synth_clip(1, 32000)
+    # ---- conditionals from a 2 s, 24 kHz reference clip (resampled to 16 kHz on the device for the tokenizer)
     ref24 = OL.synth_clip(2, 48000)
     rng = np.random.default_rng(0)
     spk = rng.standard_normal(fcfg.spk_embed_dim).astype(np.float32)
-    cond = model.prepare_conditionals(ref16, ref24, spk, prompt_text=[7, 8, 9])
+    cond = model.prepare_conditionals(ref24, spk, prompt_text=[7, 8, 9])
     n_p = cond.prompt_speech_token.shape[0]
     assert n_p == 50 and cond.prompt_mel.shape == (2 * n_p, 80)          # 2 s -> 50 tokens @ 25 Hz, 100 mel frames @ 50 Hz
     np.testing.assert_allclose(cond.prompt_mel, OL.s3gen_mel_spectrogram(ref24).T[:2 * n_p], atol=2e-3)

@@ -121,3 +121,16 @@ def test_s3gen_mel_24k(ctx):
     import mlx_swift_audio_amd as M
     with pytest.raises(M.MiaError):
         A.s3gen_mel_spectrogram(ctx, np.zeros(100, np.float32))
+
+
+def test_resample_linear(ctx):
+    """resampleAudio / linearInterpolate1d (CosyHiFTGenerator.swift:17-60) against the float32 oracle, bit for bit."""
+    from mlx_swift_audio_amd import audio as A
+    from oracle import hift as OH
+    rng = np.random.default_rng(12)
+    for n, (fr, to) in ((48000, (24000, 16000)), (16001, (16000, 24000)), (7, (24000, 16000)), (3, (48000, 16000))):
+        x = rng.standard_normal(n).astype(np.float32)
+        want = OH.linear_interpolate_1d(x[:, None], np.float32(to) / np.float32(fr))[:, 0]
+        got = A.resample_audio(ctx, x, fr, to)
+        assert got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
