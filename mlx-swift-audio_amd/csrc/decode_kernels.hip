@@ -9,6 +9,8 @@
 //
 // Roofline: a decode step is HBM-bound -- weights are streamed once (skinny MFMA GEMM, M <= 32 rows), the
 // cross-attention K/V of every clip is streamed once (dec_attention).
+#include <cstdlib>
+
 #include "decode.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -593,6 +595,179 @@ __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
   else hb.clip.pos[b] = pos + 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Greedy (temperature 0) head split over HEAD_SPLIT workgroups per clip: one workgroup per clip left 224 of the 256 CUs idle while
+// 32 of them chewed 52 k logits each (46 us per step).  Phase 1 reduces a 1/HEAD_SPLIT slice of the vocabulary to a record of
+// (max, argmax, exp-sum) pairs taken relative to the slice's own maxima; phase 2 rescales and merges the records in slice order and
+// applies exactly the decision logic of dec_head.  Sampling (temperature > 0) keeps the single-workgroup kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int HEAD_SPLIT = 8;
+constexpr int HEAD_NPT2 = 26;      // logits per thread: 256 threads * 26 * 8 slices >= V
+struct HeadRule {
+  bool active, decide, heuristic, sup_ts_all, sup_text_below_eot, sup_below_tsb;
+  int ts_floor, max_first, num_gen, cur_len;
+};
+__device__ __forceinline__ HeadRule head_rule(const HeadBufs& hb, const DecodeParams& p, int b) {
+  HeadRule r{};
+  const int pos = hb.clip.pos[b], n_initial = hb.clip.n_init[b], sot_index = hb.clip.sot_idx[b];
+  r.cur_len = pos + 1;
+  const bool generating = r.cur_len >= n_initial;
+  r.active = !(generating && hb.finished[b]) && (generating || pos == sot_index);
+  r.decide = generating;
+  r.num_gen = r.cur_len - n_initial;
+  r.max_first = p.V;
+  if (r.active && r.decide && p.timestamps) {
+    const int32_t* toks = hb.tokens + (int64_t)b * p.n_ctx;
+    const int tsb = p.timestamp_begin;
+    const int last = toks[r.cur_len - 1];
+    const bool last_was_ts = r.num_gen >= 1 && last >= tsb;
+    const bool penult_was_ts = r.num_gen < 2 || toks[r.cur_len - 2] >= tsb;
+    if (last_was_ts) { if (penult_was_ts) r.sup_ts_all = true; else r.sup_text_below_eot = true; }
+    const int lt = hb.last_ts[b];
+    if (lt > 0) r.ts_floor = penult_was_ts ? lt + 1 : lt;
+    if (r.num_gen == 0) {
+      r.sup_below_tsb = true;
+      const int last_allowed = tsb + p.max_initial_ts;
+      if (last_allowed < p.V) r.max_first = last_allowed;
+    }
+    r.heuristic = r.num_gen > 0;
+  }
+  return r;
+}
+
+struct HeadPart { float mx_text, mx_ts, s_all, s_ts, bAv, bBv, fA, fB; int bAi, bBi; };   // sums are relative to this slice's maxima
+
+__global__ __launch_bounds__(256) void dec_head_partial(HeadBufs hb, DecodeParams p, HeadPart* __restrict__ parts) {
+  __shared__ float shf[4][4];
+  __shared__ float sha[4][2];
+  __shared__ int shai[4][2];
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const HeadRule r = head_rule(hb, p, b);
+  if (!r.active) return;
+  const int V = p.V, tsb = p.timestamp_begin;
+  const float* lg = hb.logits + (int64_t)b * V;
+  const int nw = (V + 31) / 32;
+  const uint32_t* bits = hb.suppress + (r.num_gen == 0 ? nw : 0);
+  auto maskedA = [&](int i) -> bool {
+    if ((bits[i >> 5] >> (i & 31)) & 1u) return true;
+    if (p.timestamps) {
+      if (i == p.no_timestamps) return true;
+      if (r.sup_ts_all && i >= tsb) return true;
+      if (r.sup_text_below_eot && i < p.eot) return true;
+      if (i >= tsb && i < r.ts_floor) return true;
+      if (r.sup_below_tsb && i < tsb) return true;
+      if (i > r.max_first) return true;
+    }
+    return false;
+  };
+  const int base = k * (256 * HEAD_NPT2);
+  float x[HEAD_NPT2];
+#pragma unroll
+  for (int u = 0; u < HEAD_NPT2; ++u) { const int i = base + tid + 256 * u; x[u] = i < V ? lg[i] : -INFINITY; }
+  float mx_text = -INFINITY, mx_ts = -INFINITY;
+  ArgMax bA{-INFINITY, 0x7fffffff}, bB{-INFINITY, 0x7fffffff};
+  unsigned okA = 0u;
+#pragma unroll
+  for (int u = 0; u < HEAD_NPT2; ++u) {
+    const int i = base + tid + 256 * u;
+    if (i >= V) continue;
+    if (i >= tsb) mx_ts = fmaxf(mx_ts, x[u]); else mx_text = fmaxf(mx_text, x[u]);
+    if (r.decide && !maskedA(i)) {
+      okA |= 1u << u;
+      bA = amax(bA, ArgMax{x[u], i});
+      if (i >= tsb) bB = amax(bB, ArgMax{x[u], i});
+    }
+  }
+  mx_text = wave_max(mx_text); mx_ts = wave_max(mx_ts);
+  bA = wave_amax(bA); bB = wave_amax(bB);
+  if (lane == 0) { shf[wave][0] = mx_text; shf[wave][1] = mx_ts; sha[wave][0] = bA.v; shai[wave][0] = bA.i; sha[wave][1] = bB.v; shai[wave][1] = bB.i; }
+  __syncthreads();
+  mx_text = shf[0][0]; mx_ts = shf[0][1]; bA = ArgMax{sha[0][0], shai[0][0]}; bB = ArgMax{sha[0][1], shai[0][1]};
+  for (int w2 = 1; w2 < 4; ++w2) {
+    mx_text = fmaxf(mx_text, shf[w2][0]); mx_ts = fmaxf(mx_ts, shf[w2][1]);
+    bA = amax(bA, ArgMax{sha[w2][0], shai[w2][0]}); bB = amax(bB, ArgMax{sha[w2][1], shai[w2][1]});
+  }
+  const float mx_all = fmaxf(mx_text, mx_ts);
+  __syncthreads();
+  float s_all = 0.f, s_ts = 0.f, fA = 0.f, fB = 0.f;
+#pragma unroll
+  for (int u = 0; u < HEAD_NPT2; ++u) {
+    const int i = base + tid + 256 * u;
+    if (i >= V) continue;
+    s_all += __expf(x[u] - mx_all);
+    if (r.heuristic && i >= tsb) s_ts += __expf(x[u] - mx_ts);
+    if ((okA >> u) & 1u) {
+      fA += __expf(x[u] - bA.v);
+      if (r.heuristic && i >= tsb) fB += __expf(x[u] - bB.v);
+    }
+  }
+  s_all = wave_sum(s_all); s_ts = wave_sum(s_ts); fA = wave_sum(fA); fB = wave_sum(fB);
+  if (lane == 0) { shf[wave][0] = s_all; shf[wave][1] = s_ts; shf[wave][2] = fA; shf[wave][3] = fB; }
+  __syncthreads();
+  if (tid == 0) {
+    s_all = s_ts = fA = fB = 0.f;
+    for (int w2 = 0; w2 < 4; ++w2) { s_all += shf[w2][0]; s_ts += shf[w2][1]; fA += shf[w2][2]; fB += shf[w2][3]; }
+    parts[b * HEAD_SPLIT + k] = HeadPart{mx_text, mx_ts, s_all, s_ts, bA.v, bB.v, fA, fB, bA.i, bB.i};
+  }
+}
+
+// merge the slice records in slice order (deterministic), decide, update the clip's state (same tail as dec_head)
+__global__ __launch_bounds__(64) void dec_head_final(HeadBufs hb, DecodeParams p, const HeadPart* __restrict__ parts) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const int pos = hb.clip.pos[b];
+  const int n_initial = hb.clip.n_init[b], sot_index = hb.clip.sot_idx[b];
+  const HeadRule r = head_rule(hb, p, b);
+  if (!r.active) {
+    const bool generating = r.cur_len >= n_initial;
+    if (!generating) hb.clip.pos[b] = pos + 1;        // forced token, no probe: just advance (a finished clip idles)
+    return;
+  }
+  const int V = p.V, tsb = p.timestamp_begin;
+  const float* lg = hb.logits + (int64_t)b * V;
+  int32_t* toks = hb.tokens + (int64_t)b * p.n_ctx;
+  const HeadPart* pt = parts + b * HEAD_SPLIT;
+  float mx_text = -INFINITY, mx_ts = -INFINITY;
+  ArgMax bA{-INFINITY, 0x7fffffff}, bB{-INFINITY, 0x7fffffff};
+  for (int k = 0; k < HEAD_SPLIT; ++k) {
+    mx_text = fmaxf(mx_text, pt[k].mx_text); mx_ts = fmaxf(mx_ts, pt[k].mx_ts);
+    bA = amax(bA, ArgMax{pt[k].bAv, pt[k].bAi}); bB = amax(bB, ArgMax{pt[k].bBv, pt[k].bBi});
+  }
+  const float mx_all = fmaxf(mx_text, mx_ts);
+  float s_all = 0.f, s_ts = 0.f, fA = 0.f, fB = 0.f;
+  for (int k = 0; k < HEAD_SPLIT; ++k) {
+    const float ml = fmaxf(pt[k].mx_text, pt[k].mx_ts);
+    if (ml > -INFINITY) s_all += pt[k].s_all * __expf(ml - mx_all);
+    if (pt[k].mx_ts > -INFINITY) s_ts += pt[k].s_ts * __expf(pt[k].mx_ts - mx_ts);
+    if (pt[k].bAv > -INFINITY) fA += pt[k].fA * __expf(pt[k].bAv - bA.v);
+    if (pt[k].bBv > -INFINITY) fB += pt[k].fB * __expf(pt[k].bBv - bB.v);
+  }
+  const float lse = mx_all + __logf(s_all);
+  if (pos == sot_index) hb.no_speech[b] = __expf(lg[p.no_speech] - lse);
+  if (!r.decide) { hb.clip.pos[b] = pos + 1; return; }
+  bool useB = false;
+  if (r.heuristic) {
+    const float ts_lse = (mx_ts - lse) + __logf(s_ts);
+    const float max_text = mx_text - lse;
+    useB = ts_lse > max_text;
+  }
+  const ArgMax best = useB ? bB : bA;
+  const float fsum = useB ? fB : fA;
+  const bool all_masked = best.i == 0x7fffffff;
+  const int next = all_masked ? 0 : best.i;
+  if (next != p.eot) {
+    hb.sum_logprob[b] += all_masked ? __int_as_float(0x7fc00000) : (lg[next] - best.v) - __logf(fsum);
+    hb.n_logprob[b] += 1;
+  }
+  toks[r.cur_len] = next;
+  hb.n_gen[b] = r.num_gen + 1;
+  if (next > tsb) hb.last_ts[b] = next;
+  int cap = p.max_tokens - n_initial;
+  if (p.max_new_tokens > 0 && p.max_new_tokens < cap) cap = p.max_new_tokens;
+  if (next == p.eot || r.num_gen + 1 >= cap) hb.finished[b] = 1;
+  else hb.clip.pos[b] = pos + 1;
+}
+
 // compact outputs: generated tokens with EOT (and anything after) stripped; avg_logprob
 __global__ void dec_finalize(const int32_t* __restrict__ tokens, const int32_t* __restrict__ n_gen,
                              const float* __restrict__ sum_lp, const int32_t* __restrict__ n_lp, int32_t* __restrict__ out_tokens,
@@ -679,6 +854,14 @@ int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const vo
 int dec_launch_head(mia_whisper* w, int32_t* last_ts, const DecodeParams& p, hipStream_t s) {
   if (p.V > 1024 * HEAD_NPT) return -1;
   HeadBufs hb{w->logits, w->tokens, w->n_gen, w->finished, last_ts, w->sum_logprob, w->n_logprob, w->no_speech, w->suppress_bits, w->uniforms, w->clip};
+  static const bool one_block = getenv("MIA_HEAD_SINGLE") != nullptr;
+  if (p.greedy && !one_block && p.V <= 256 * HEAD_NPT2 * HEAD_SPLIT) {
+    // argmax path: the vocabulary is reduced by HEAD_SPLIT workgroups per clip, then merged (w->partial is free at this point of the step)
+    HeadPart* parts = reinterpret_cast<HeadPart*>(w->partial);
+    hipLaunchKernelGGL(dec_head_partial, dim3(HEAD_SPLIT, w->cur_B), dim3(256), 0, s, hb, p, parts);
+    hipLaunchKernelGGL(dec_head_final, dim3(w->cur_B), dim3(64), 0, s, hb, p, (const HeadPart*)parts);
+    return 0;
+  }
   hipLaunchKernelGGL(dec_head, dim3(w->cur_B), dim3(1024), 0, s, hb, p);
   return 0;
 }

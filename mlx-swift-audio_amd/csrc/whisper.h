@@ -54,6 +54,7 @@ struct DecodeParams {  // immutable per graph (kernel argument, by value)
   int B, V, D, H, L, n_ctx;     // n_ctx = n_text_ctx (448)
   int eot, no_speech, no_timestamps, timestamp_begin;
   int timestamps, max_tokens, max_initial_ts, max_new_tokens;
+  int greedy;                   // every clip decodes at temperature 0: the argmax head may be split over several workgroups
 };
 
 struct mia_whisper {

@@ -173,6 +173,7 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
     }
     MIA_HIP(ctx, hipStreamSynchronize(s));   // host vectors go out of scope
   }
+  p.greedy = any_sampling ? 0 : 1;
   MIA_HIP(ctx, hipMemsetAsync(w->n_gen, 0, (size_t)B * 4, s));
   MIA_HIP(ctx, hipMemsetAsync(w->last_ts, 0, (size_t)B * 4, s));
   MIA_HIP(ctx, hipMemsetAsync(w->sum_logprob, 0, (size_t)B * 4, s));
