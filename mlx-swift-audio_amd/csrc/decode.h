@@ -22,5 +22,6 @@ int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s);
 // qk_out (optional): pre-softmax scores of the heads with head_slot[h] >= 0 -> qk_out[b][slot][pos[b]][key] (word-timestamp alignment)
 int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const void* vc, void* out, int fixed_keys, int cap_keys,
                          hipStream_t s, float* qk_out = nullptr, const int32_t* head_slot = nullptr, int n_slots = 0, int qk_ctx = 0);
+bool dec_head_is_split(const DecodeParams& p);
 int dec_launch_head(mia_whisper* w, int32_t* last_ts, const DecodeParams& p, hipStream_t s);
 int dec_launch_finalize(mia_whisper* w, int32_t* out_n, const DecodeParams& p, hipStream_t s);

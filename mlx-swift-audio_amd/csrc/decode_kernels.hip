@@ -711,61 +711,94 @@ __global__ __launch_bounds__(256) void dec_head_partial(HeadBufs hb, DecodeParam
   }
 }
 
-// merge the slice records in slice order (deterministic), decide, update the clip's state (same tail as dec_head)
-__global__ __launch_bounds__(64) void dec_head_final(HeadBufs hb, DecodeParams p, const HeadPart* __restrict__ parts) {
-  const int b = blockIdx.x;
-  if (threadIdx.x != 0) return;
-  const int pos = hb.clip.pos[b];
-  const int n_initial = hb.clip.n_init[b], sot_index = hb.clip.sot_idx[b];
-  const HeadRule r = head_rule(hb, p, b);
-  if (!r.active) {
-    const bool generating = r.cur_len >= n_initial;
-    if (!generating) hb.clip.pos[b] = pos + 1;        // forced token, no probe: just advance (a finished clip idles)
-    return;
+// merge the slice records in slice order (deterministic), decide, update the clip's state (same tail as dec_head); then, if the clip
+// advanced, embed the token of the NEW position and apply the first LayerNorm of the next step (replaces that step's dec_embed_ln launch)
+struct NextEmbed { const uint16_t* emb; const float* pos_emb; const float* gamma; const float* beta; float* x; uint16_t* h; int D; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void dec_head_final(HeadBufs hb, DecodeParams p, const HeadPart* __restrict__ parts, NextEmbed ne) {
+  __shared__ int s_newpos;
+  __shared__ float sh[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int newpos = -1;
+    const int pos = hb.clip.pos[b];
+    const int n_initial = hb.clip.n_init[b], sot_index = hb.clip.sot_idx[b];
+    const HeadRule r = head_rule(hb, p, b);
+    if (!r.active) {
+      if (r.cur_len < n_initial) newpos = pos + 1;    // forced token, no probe: just advance (a finished clip idles)
+    } else {
+      const int V = p.V, tsb = p.timestamp_begin;
+      const float* lg = hb.logits + (int64_t)b * V;
+      int32_t* toks = hb.tokens + (int64_t)b * p.n_ctx;
+      const HeadPart* pt = parts + b * HEAD_SPLIT;
+      float mx_text = -INFINITY, mx_ts = -INFINITY;
+      ArgMax bA{-INFINITY, 0x7fffffff}, bB{-INFINITY, 0x7fffffff};
+      for (int k = 0; k < HEAD_SPLIT; ++k) {
+        mx_text = fmaxf(mx_text, pt[k].mx_text); mx_ts = fmaxf(mx_ts, pt[k].mx_ts);
+        bA = amax(bA, ArgMax{pt[k].bAv, pt[k].bAi}); bB = amax(bB, ArgMax{pt[k].bBv, pt[k].bBi});
+      }
+      const float mx_all = fmaxf(mx_text, mx_ts);
+      float s_all = 0.f, s_ts = 0.f, fA = 0.f, fB = 0.f;
+      for (int k = 0; k < HEAD_SPLIT; ++k) {
+        const float ml = fmaxf(pt[k].mx_text, pt[k].mx_ts);
+        if (ml > -INFINITY) s_all += pt[k].s_all * __expf(ml - mx_all);
+        if (pt[k].mx_ts > -INFINITY) s_ts += pt[k].s_ts * __expf(pt[k].mx_ts - mx_ts);
+        if (pt[k].bAv > -INFINITY) fA += pt[k].fA * __expf(pt[k].bAv - bA.v);
+        if (pt[k].bBv > -INFINITY) fB += pt[k].fB * __expf(pt[k].bBv - bB.v);
+      }
+      const float lse = mx_all + __logf(s_all);
+      if (pos == sot_index) hb.no_speech[b] = __expf(lg[p.no_speech] - lse);
+      if (!r.decide) newpos = pos + 1;
+      else {
+        bool useB = false;
+        if (r.heuristic) {
+          const float ts_lse = (mx_ts - lse) + __logf(s_ts);
+          const float max_text = mx_text - lse;
+          useB = ts_lse > max_text;
+        }
+        const ArgMax best = useB ? bB : bA;
+        const float fsum = useB ? fB : fA;
+        const bool all_masked = best.i == 0x7fffffff;
+        const int next = all_masked ? 0 : best.i;
+        if (next != p.eot) {
+          hb.sum_logprob[b] += all_masked ? __int_as_float(0x7fc00000) : (lg[next] - best.v) - __logf(fsum);
+          hb.n_logprob[b] += 1;
+        }
+        toks[r.cur_len] = next;
+        hb.n_gen[b] = r.num_gen + 1;
+        if (next > tsb) hb.last_ts[b] = next;
+        int cap = p.max_tokens - n_initial;
+        if (p.max_new_tokens > 0 && p.max_new_tokens < cap) cap = p.max_new_tokens;
+        if (next == p.eot || r.num_gen + 1 >= cap) hb.finished[b] = 1;
+        else newpos = pos + 1;
+      }
+    }
+    if (newpos >= 0) hb.clip.pos[b] = newpos;
+    s_newpos = newpos;
   }
-  const int V = p.V, tsb = p.timestamp_begin;
-  const float* lg = hb.logits + (int64_t)b * V;
-  int32_t* toks = hb.tokens + (int64_t)b * p.n_ctx;
-  const HeadPart* pt = parts + b * HEAD_SPLIT;
-  float mx_text = -INFINITY, mx_ts = -INFINITY;
-  ArgMax bA{-INFINITY, 0x7fffffff}, bB{-INFINITY, 0x7fffffff};
-  for (int k = 0; k < HEAD_SPLIT; ++k) {
-    mx_text = fmaxf(mx_text, pt[k].mx_text); mx_ts = fmaxf(mx_ts, pt[k].mx_ts);
-    bA = amax(bA, ArgMax{pt[k].bAv, pt[k].bAi}); bB = amax(bB, ArgMax{pt[k].bBv, pt[k].bBi});
+  __syncthreads();
+  const int np_ = s_newpos;
+  if (np_ < 0 || np_ >= p.n_ctx) return;
+  // ---- x[b] = E[token[b][np]] + P[np];  h[b] = LN(x[b])   (the next step's TextDecoder.swift:67 + first attn_ln)
+  const int D = ne.D, nv = D >> 2;
+  const int tok = hb.tokens[(int64_t)b * p.n_ctx + np_];
+  const uint16_t* e = ne.emb + (int64_t)tok * D;
+  const float* pe = ne.pos_emb + (int64_t)np_ * D;
+  float* xr = ne.x + (int64_t)b * D;
+  f32x4 v[ROW_NV];
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const int c = tid + 256 * i;
+    if (c < nv) {
+      const s16x4 ev = *reinterpret_cast<const s16x4*>(e + 4 * c);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pe + 4 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = T::to_f32((uint16_t)ev[j]) + pv[j];
+      *reinterpret_cast<f32x4*>(xr + 4 * c) = v[i];
+    } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const float mx_all = fmaxf(mx_text, mx_ts);
-  float s_all = 0.f, s_ts = 0.f, fA = 0.f, fB = 0.f;
-  for (int k = 0; k < HEAD_SPLIT; ++k) {
-    const float ml = fmaxf(pt[k].mx_text, pt[k].mx_ts);
-    if (ml > -INFINITY) s_all += pt[k].s_all * __expf(ml - mx_all);
-    if (pt[k].mx_ts > -INFINITY) s_ts += pt[k].s_ts * __expf(pt[k].mx_ts - mx_ts);
-    if (pt[k].bAv > -INFINITY) fA += pt[k].fA * __expf(pt[k].bAv - bA.v);
-    if (pt[k].bBv > -INFINITY) fB += pt[k].fB * __expf(pt[k].bBv - bB.v);
-  }
-  const float lse = mx_all + __logf(s_all);
-  if (pos == sot_index) hb.no_speech[b] = __expf(lg[p.no_speech] - lse);
-  if (!r.decide) { hb.clip.pos[b] = pos + 1; return; }
-  bool useB = false;
-  if (r.heuristic) {
-    const float ts_lse = (mx_ts - lse) + __logf(s_ts);
-    const float max_text = mx_text - lse;
-    useB = ts_lse > max_text;
-  }
-  const ArgMax best = useB ? bB : bA;
-  const float fsum = useB ? fB : fA;
-  const bool all_masked = best.i == 0x7fffffff;
-  const int next = all_masked ? 0 : best.i;
-  if (next != p.eot) {
-    hb.sum_logprob[b] += all_masked ? __int_as_float(0x7fc00000) : (lg[next] - best.v) - __logf(fsum);
-    hb.n_logprob[b] += 1;
-  }
-  toks[r.cur_len] = next;
-  hb.n_gen[b] = r.num_gen + 1;
-  if (next > tsb) hb.last_ts[b] = next;
-  int cap = p.max_tokens - n_initial;
-  if (p.max_new_tokens > 0 && p.max_new_tokens < cap) cap = p.max_new_tokens;
-  if (next == p.eot || r.num_gen + 1 >= cap) hb.finished[b] = 1;
-  else hb.clip.pos[b] = pos + 1;
+  row_layernorm_store<T>(v, nv, D, ne.gamma, ne.beta, ne.h + (int64_t)b * D, sh);
 }
 
 // compact outputs: generated tokens with EOT (and anything after) stripped; avg_logprob
@@ -851,15 +884,24 @@ int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const vo
   return 0;
 }
 
+// true when the greedy head runs as partial + final kernels; the final kernel then also embeds the next position, so the step graph
+// carries no dec_embed_ln of its own (the caller launches it once before the first step)
+bool dec_head_is_split(const DecodeParams& p) {
+  static const bool one_block = getenv("MIA_HEAD_SINGLE") != nullptr;
+  return p.greedy && !one_block && p.V <= 256 * HEAD_NPT2 * HEAD_SPLIT;
+}
+
 int dec_launch_head(mia_whisper* w, int32_t* last_ts, const DecodeParams& p, hipStream_t s) {
   if (p.V > 1024 * HEAD_NPT) return -1;
   HeadBufs hb{w->logits, w->tokens, w->n_gen, w->finished, last_ts, w->sum_logprob, w->n_logprob, w->no_speech, w->suppress_bits, w->uniforms, w->clip};
-  static const bool one_block = getenv("MIA_HEAD_SINGLE") != nullptr;
-  if (p.greedy && !one_block && p.V <= 256 * HEAD_NPT2 * HEAD_SPLIT) {
+  if (dec_head_is_split(p)) {
     // argmax path: the vocabulary is reduced by HEAD_SPLIT workgroups per clip, then merged (w->partial is free at this point of the step)
     HeadPart* parts = reinterpret_cast<HeadPart*>(w->partial);
     hipLaunchKernelGGL(dec_head_partial, dim3(HEAD_SPLIT, w->cur_B), dim3(256), 0, s, hb, p, parts);
-    hipLaunchKernelGGL(dec_head_final, dim3(w->cur_B), dim3(64), 0, s, hb, p, (const HeadPart*)parts);
+    const LNW& ln0 = w->dec[0].attn_ln;
+    NextEmbed ne{(const uint16_t*)w->tok_emb, w->dec_pos, ln0.g, ln0.b, w->dx, (uint16_t*)w->dh, w->dims.n_text_state};
+    if (w->dtype == MIA_F16) hipLaunchKernelGGL(dec_head_final<F16>, dim3(w->cur_B), dim3(256), 0, s, hb, p, (const HeadPart*)parts, ne);
+    else hipLaunchKernelGGL(dec_head_final<BF16>, dim3(w->cur_B), dim3(256), 0, s, hb, p, (const HeadPart*)parts, ne);
     return 0;
   }
   hipLaunchKernelGGL(dec_head, dim3(w->cur_B), dim3(1024), 0, s, hb, p);

@@ -67,7 +67,8 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p, const AlignHook* hook = 
     return dec_launch_skinny(w, a, mode, s);
   };
   const int S_d = pick_split(D, 2), S_4d = pick_split(4 * D, 4);   // x 4 waves of intra-workgroup split-K each
-  dec_launch_embed_ln(w, w->dec[0].attn_ln, s);
+  // (the split greedy head embeds the next position itself: only the very first step needs this launch, done by the caller)
+  if (hook || !dec_head_is_split(p)) dec_launch_embed_ln(w, w->dec[0].attn_ln, s);
   for (int l = 0; l < p.L; ++l) {
     const DecBlockW& b = w->dec[l];
     uint16_t* sk = (uint16_t*)w->self_k + (size_t)l * w->cap_B * C * D;
@@ -200,6 +201,7 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
     w->graph_valid = true;
   }
 
+  if (dec_head_is_split(p)) dec_launch_embed_ln(w, w->dec[0].attn_ln, s);   // position 0; later positions are embedded by the head
   int prof_rec = mia_prof_begin(ctx, MIA_PROF_DECODE, 0.0);
   int steps_run = 0;
   const int min_init = *std::min_element(n_init.begin(), n_init.end());
