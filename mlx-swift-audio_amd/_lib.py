@@ -113,8 +113,24 @@ class Context:
     def stream(self) -> int:
         return int(self.lib.mia_stream(self.h) or 0)
 
+    def adopt(self, child) -> None:
+        """Model handles register here: they must be released BEFORE the context (their free() synchronises on its stream).  Weak
+        references: adoption never extends a model's life."""
+        import weakref
+        if not hasattr(self, "_children"):
+            self._children = []
+        self._children.append(weakref.ref(child))
+
     def close(self) -> None:
         if getattr(self, "h", None):
+            for ref in getattr(self, "_children", []):
+                obj = ref()
+                if obj is not None:
+                    try:
+                        obj.close()
+                    except Exception:
+                        pass
+            self._children = []
             self.lib.mia_destroy(self.h)
             self.h = None
 

@@ -57,6 +57,7 @@ def _views(weights):
 class _Codec:
     def __init__(self, ctx, h, cfg):
         self.ctx, self.h, self.cfg = ctx, h, cfg
+        ctx.adopt(self)
 
     def output_len(self, latent_len: int) -> int:
         return int(self.ctx.lib.mia_codec_output_len(self.h, latent_len))
@@ -65,7 +66,7 @@ class _Codec:
         return int(self.ctx.lib.mia_codec_noise_len(self.h, latent_len))
 
     def close(self):
-        if self.h:
+        if self.h and getattr(self.ctx, 'h', None):
             self.ctx.lib.mia_codec_free(self.h)
             self.h = None
 

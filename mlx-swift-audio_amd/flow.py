@@ -34,6 +34,7 @@ def _declare(lib):
 class FlowModule:
     def __init__(self, ctx, h, cfg):
         self.ctx, self.h, self.cfg = ctx, h, cfg
+        ctx.adopt(self)
 
     @staticmethod
     def load(ctx: _lib.Context, cfg, weights: dict[str, np.ndarray]) -> "FlowModule":
@@ -53,7 +54,7 @@ class FlowModule:
         return FlowModule(ctx, h, cfg)
 
     def close(self):
-        if self.h:
+        if self.h and getattr(self.ctx, 'h', None):
             self.ctx.lib.mia_flow_free(self.h)
             self.h = None
 

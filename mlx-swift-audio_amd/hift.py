@@ -49,6 +49,7 @@ def _pad4(v):
 class HiFTGenerator:
     def __init__(self, ctx, h, cfg):
         self.ctx, self.h, self.cfg = ctx, h, cfg
+        ctx.adopt(self)
         self.up = ctx.lib.mia_hift_upsample_factor(h)
 
     @staticmethod
@@ -72,7 +73,7 @@ class HiFTGenerator:
         return HiFTGenerator(ctx, h, cfg)
 
     def close(self):
-        if self.h:
+        if self.h and getattr(self.ctx, 'h', None):
             self.ctx.lib.mia_hift_free(self.h)
             self.h = None
 

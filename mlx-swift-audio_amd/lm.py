@@ -50,6 +50,7 @@ def _declare(lib):
 class CausalLM:
     def __init__(self, ctx, h, cfg):
         self.ctx, self.h, self.cfg = ctx, h, cfg
+        ctx.adopt(self)
 
     @staticmethod
     def load(ctx: _lib.Context, cfg, weights: dict[str, np.ndarray], dtype: int = _lib.BF16) -> "CausalLM":
@@ -73,7 +74,7 @@ class CausalLM:
         return CausalLM(ctx, h, cfg)
 
     def close(self):
-        if self.h:
+        if self.h and getattr(self.ctx, 'h', None):
             self.ctx.lib.mia_lm_free(self.h)
             self.h = None
 

@@ -42,6 +42,7 @@ def merge_tokenized_segments(segments, overlap=4, token_rate=25):
 class S3Tokenizer:
     def __init__(self, ctx, h, cfg):
         self.ctx, self.h, self.cfg = ctx, h, cfg
+        ctx.adopt(self)
 
     @staticmethod
     def load(ctx: _lib.Context, cfg, weights: dict[str, np.ndarray]) -> "S3Tokenizer":
@@ -59,7 +60,7 @@ class S3Tokenizer:
         return S3Tokenizer(ctx, h, cfg)
 
     def close(self):
-        if self.h:
+        if self.h and getattr(self.ctx, 'h', None):
             self.ctx.lib.mia_s3tok_free(self.h)
             self.h = None
 

@@ -129,6 +129,7 @@ class WhisperModel:
 
     def __init__(self, ctx: _lib.Context, handle, dims, dtype):
         self.ctx, self.h, self.dims, self.dtype = ctx, handle, dims, dtype
+        ctx.adopt(self)
         self.special = SpecialTokens.for_vocab(dims.n_vocab)
         self._keep = []
 
@@ -153,7 +154,7 @@ class WhisperModel:
         return WhisperModel(ctx, h, dims, dtype)
 
     def close(self):
-        if self.h:
+        if self.h and getattr(self.ctx, 'h', None):
             self.ctx.lib.mia_whisper_free(self.h)
             self.h = None
 

@@ -241,3 +241,26 @@ def test_transcribe_loop_hip_vs_oracle(ctx):
             assert g.segments[0].tokens == r.segments[0].tokens
             assert abs(g.segments[0].start - r.segments[0].start) < 1e-6 and abs(g.segments[0].end - r.segments[0].end) < 1e-6
     model.close()
+
+
+def test_batch_invariance_above_one_row_tile(ctx):
+    """40 clips in one batch (two 32-row tiles of the skinny GEMMs, ragged last tile) decode exactly like the same clips in batches of 8:
+    per-clip results must not depend on batch composition (the path shards by clip)."""
+    from mlx_swift_audio_amd import whisper as HW
+    dims, oracle, model = _models(ctx, "micro.en", "f16", seed=5)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    mel = _mel(dims, 40, 17, "f16")
+    o = HW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=10)
+    big = HW.GreedyDecoder(model, o).decode(mel)
+    model.encode(mel)
+    feats_big = model.audio_features().copy()
+    small = []
+    for i in range(0, 40, 8):
+        small += HW.GreedyDecoder(model, o).decode(mel[i:i + 8])
+    assert len(big) == len(small) == 40
+    for a, b in zip(big, small):
+        assert a.tokens == b.tokens
+        assert a.avg_logprob == pytest.approx(b.avg_logprob, rel=1e-5, abs=1e-6, nan_ok=True)
+    model.encode(mel[32:40])
+    np.testing.assert_array_equal(model.audio_features(), feats_big[32:40])
+    model.close()
