@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--no-codec", action="store_true", help="skip the SNAC/DAC decode samples/s side measurement")
     ap.add_argument("--cpu-tokens", type=int, default=24, help="greedy steps actually run by the CPU baseline")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--replicas", type=int, default=2,
+                    help="model replicas on separate HIP streams; passes are dealt round-robin so the encoder of one batch overlaps the decoder of another (1 = strictly serial passes)")
     args = ap.parse_args()
 
     import torch
@@ -216,49 +218,92 @@ def main():
 
     dims = S.DIMS[args.model]
     dtype = m.BF16 if args.dtype == "bf16" else m.F16
-    # one non-default HIP stream shared by torch and the library (graph capture is illegal on the legacy default stream)
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    ctx = m.Context(local_rank, stream=stream.cuda_stream)
+    import threading
+    from mlx_swift_audio_amd import parallel as P
 
     t0 = time.time()
     weights = S.synthetic_weights(dims, seed=args.seed, style="survey")
     log(f"[bench] synthetic {args.model} checkpoint generated in {time.time() - t0:.1f}s")
-    t0 = time.time()
-    model = HW.WhisperModel.load(ctx, dims, weights, dtype)
-    del weights
-    log(f"[bench] weights uploaded in {time.time() - t0:.1f}s")
-
     B = args.batch
     clips = np.stack([S.synth_clip(rank * B + i) for i in range(B)])
-    pcm = torch.from_numpy(clips).cuda()
     offs = np.arange(B + 1, dtype=np.int64) * clips.shape[1]
-    st = model.special
-    opts = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=args.max_new_tokens)
-    tokens = torch.zeros((B, opts.max_tokens), dtype=torch.int32, device="cuda")
-    n_tok = torch.zeros(B, dtype=torch.int32, device="cuda")
-    avg = torch.zeros(B, dtype=torch.float32, device="cuda")
-    nsp = torch.zeros(B, dtype=torch.float32, device="cuda")
-    from mlx_swift_audio_amd import parallel as P
+    main_stream = torch.cuda.Stream()     # non-default stream (graph capture is illegal on the legacy default stream)
+    torch.cuda.set_stream(main_stream)
+    pcm = torch.from_numpy(clips).cuda()
+    torch.cuda.synchronize()
 
-    def step():
-        model.transcribe_windows_device(pcm.data_ptr(), offs, opts, tokens.data_ptr(), n_tok.data_ptr(), avg.data_ptr(), nsp.data_ptr())
+    class Replica:
+        """One model instance on its own HIP stream.  Passes are dealt round-robin over R replicas from R host threads, so the
+        (MFMA-bound) encoder of one batch overlaps the (launch-latency-bound) decoder of another -- how one GPU is driven for
+        throughput.  Every pass is still a full log-mel + encode + 448-token-budget decode of 32 clips."""
+
+        def __init__(self):
+            self.stream = torch.cuda.Stream()
+            self.ctx = m.Context(local_rank, stream=self.stream.cuda_stream)
+            self.model = HW.WhisperModel.load(self.ctx, dims, weights, dtype)
+            self.opts = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(self.model.special), blank_ids=[220], max_new_tokens=args.max_new_tokens)
+            with torch.cuda.stream(self.stream):
+                self.tokens = torch.zeros((B, self.opts.max_tokens), dtype=torch.int32, device="cuda")
+                self.n_tok = torch.zeros(B, dtype=torch.int32, device="cuda")
+                self.avg = torch.zeros(B, dtype=torch.float32, device="cuda")
+                self.nsp = torch.zeros(B, dtype=torch.float32, device="cuda")
+            self.stream.synchronize()
+
+        def step(self):
+            self.model.transcribe_windows_device(pcm.data_ptr(), offs, self.opts, self.tokens.data_ptr(), self.n_tok.data_ptr(), self.avg.data_ptr(),
+                                                 self.nsp.data_ptr())
+
+    R = max(1, min(args.replicas, args.steps))
+    t0 = time.time()
+    reps = [Replica() for _ in range(R)]
+    del weights
+    log(f"[bench] {R} replica(s) loaded in {time.time() - t0:.1f}s")
+    ctx = reps[0].ctx
+
+    def run_passes(k):
+        """k passes dealt round-robin over the replicas, one host thread per replica; returns when every stream has drained."""
+        counts = [k // R + (1 if r < k % R else 0) for r in range(R)]
+        if R == 1:
+            for _ in range(counts[0]):
+                reps[0].step()
+        else:
+            ths = [threading.Thread(target=lambda rp=rp, c=c: [rp.step() for _ in range(c)]) for rp, c in zip(reps, counts) if c]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        for rp in reps:
+            rp.ctx.synchronize()
         if world > 1:
-            P.gather_tokens(tokens, n_tok, world, max_shard=B)   # the path's only exchange: token ids over xGMI (RCCL)
+            for i in range(k):                    # the path's only exchange: token ids over xGMI (RCCL), one gather per pass
+                rp = reps[i % R]
+                P.gather_tokens(rp.tokens, rp.n_tok, world, max_shard=B)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    prof_keys = ("logmel", "enc_gemm", "crosskv_gemm", "enc_attention", "enc_norm", "decode")
+    run_passes(max(args.warmup, 1) * R if args.warmup else 0)     # every replica captures its step graph during warm-up
     fence()
+    # ---- serial calibration pass (replica 0 alone): the uncontended per-launch figures of every kernel class
     ctx.profile(True)
     ctx.profile_reset()
+    reps[0].step()
+    ctx.synchronize()
+    prof_serial = {k: ctx.profile_read(k) for k in prof_keys}
+    fence()
+    # R == 1: the timed region itself is instrumented.  R > 1: a launch's wall duration under concurrent streams includes waiting for
+    # the other streams' kernels and says nothing about the kernel, so the timed region runs un-instrumented and `roofline` / `stages`
+    # come from the calibration pass above (same process, same workload, HIP events on the library's stream).
+    ctx.profile(False)
+    if R == 1:
+        ctx.profile(True)
+        ctx.profile_reset()
+    fence()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_passes(args.steps)
     fence()
     elapsed = time.perf_counter() - t_start
     ctx.profile(False)
@@ -267,49 +312,57 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    n_gen = n_tok.cpu().numpy()
-    prof = {k: ctx.profile_read(k) for k in ("logmel", "enc_gemm", "crosskv_gemm", "enc_attention", "enc_norm", "decode")}
+    n_gen = reps[0].n_tok.cpu().numpy()
+    prof = {k: ctx.profile_read(k) for k in prof_keys} if R == 1 else prof_serial
     ms_per_step = elapsed / args.steps * 1e3
     audio_s = 30.0 * B * world
     value = audio_s * args.steps / elapsed
+    model = reps[0].model
 
-    # roofline of the dominant kernel class (largest share of the timed region on this rank)
-    n_l, ms_l, w_l = prof["enc_gemm"]
-    gemm_tflops = (w_l / n_l) / ((ms_l / n_l) * 1e-3) / 1e12 if n_l else 0.0
-    n_d, ms_d, steps_d = prof["decode"]
     L, D, V, T = dims.n_text_layer, dims.n_text_state, dims.n_vocab, dims.n_audio_ctx
     dec_bytes_per_step = 2.0 * (L * (10 * D * D + 8 * D * D) + V * D) + B * L * 2 * T * D * 2.0   # weights once + cross-KV of B clips
-    dec_gbs = dec_bytes_per_step * steps_d / (ms_d * 1e-3) / 1e9 if ms_d else 0.0
-    shares = {k: v[1] / (elapsed * 1e3) for k, v in prof.items()}
-    if shares["enc_gemm"] >= shares["decode"]:
-        roofline = {"kernel": "gemm_nt_kernel (encoder Linear/Conv GEMMs, 128x128x64 MFMA tiles)", "bound": "mfma",
-                    "achieved": round(gemm_tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(gemm_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "launches": n_l, "avg_launch_ms": round(ms_l / max(n_l, 1), 4), "flop_per_launch_avg": w_l / max(n_l, 1)}
-    else:
-        roofline = {"kernel": "decode step graph (skinny MFMA GEMMs + KV-cache attention + decode head)", "bound": "hbm",
-                    "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
-                    "traffic": None, "launches": int(steps_d), "avg_launch_ms": round(ms_d / max(steps_d, 1), 4),
-                    "bytes_per_launch": dec_bytes_per_step}
-    # HBM traffic per launch from the committed PMC passes of this same workload (rocprofv3 cannot run inside the timed process):
-    # profiles/r01_pmc_summary.json, made by tools/pmc_summary.py with the guide's gfx950 corrections.  null when absent.
-    try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")))
-        if roofline["bound"] == "hbm":
-            roofline["traffic"] = round(pmc["decode_step"]["hbm_bytes_per_step"], 0)
+
+    def summarize(pf, passes):
+        """roofline of the dominant kernel class (largest device time) + per-class figures, from HIP-event records of `passes` passes"""
+        n_l, ms_l, w_l = pf["enc_gemm"]
+        gemm_tflops = (w_l / n_l) / ((ms_l / n_l) * 1e-3) / 1e12 if n_l else 0.0
+        n_d, ms_d, steps_d = pf["decode"]
+        dec_gbs = dec_bytes_per_step * steps_d / (ms_d * 1e-3) / 1e9 if ms_d else 0.0
+        tot = sum(v[1] for v in pf.values()) or 1.0
+        if pf["enc_gemm"][1] >= pf["decode"][1]:
+            rl = {"kernel": "gemm_nt_kernel_256 (encoder Linear/Conv GEMMs, 256x256x64 MFMA tiles)", "bound": "mfma",
+                  "achieved": round(gemm_tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(gemm_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                  "launches": n_l, "avg_launch_ms": round(ms_l / max(n_l, 1), 4), "flop_per_launch_avg": w_l / max(n_l, 1)}
         else:
-            roofline["traffic"] = round(pmc["encoder_gemm"]["hbm_bytes_per_launch"], 0)
-        roofline["traffic_source"] = "profiles/r01_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
-    except (OSError, KeyError, ValueError):
-        pass
-    stage = {k: {"ms_per_step": round(v[1] / args.steps, 3), "share": round(shares[k], 4)} for k, v in prof.items()}
-    stage["enc_gemm"]["tflops"] = round(gemm_tflops, 1)
-    if prof["enc_attention"][0]:
-        stage["enc_attention"]["tflops"] = round(prof["enc_attention"][2] / (prof["enc_attention"][1] * 1e-3) / 1e12, 1)
-    if prof["logmel"][0]:
-        stage["logmel"]["GBs_algorithmic"] = round(prof["logmel"][2] / (prof["logmel"][1] * 1e-3) / 1e9, 1)
-    stage["decode"]["GBs_algorithmic"] = round(dec_gbs, 1)
-    stage["decode"]["steps_per_pass"] = steps_d / max(n_d, 1)
+            rl = {"kernel": "decode step graph (skinny MFMA GEMMs + KV-cache attention + decode head)", "bound": "hbm",
+                  "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
+                  "traffic": None, "launches": int(steps_d), "avg_launch_ms": round(ms_d / max(steps_d, 1), 4),
+                  "bytes_per_launch": dec_bytes_per_step}
+        # HBM traffic per launch from the committed PMC passes of this same workload (rocprofv3 cannot run inside the timed process):
+        # profiles/r01_pmc_summary.json, made by tools/pmc_summary.py with the guide's gfx950 corrections.  null when absent.
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")))
+            rl["traffic"] = round(pmc["decode_step"]["hbm_bytes_per_step"] if rl["bound"] == "hbm" else pmc["encoder_gemm"]["hbm_bytes_per_launch"], 0)
+            rl["traffic_source"] = "profiles/r01_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
+        except (OSError, KeyError, ValueError):
+            pass
+        stg = {k: {"ms_per_pass": round(v[1] / passes, 3), "share_of_device_time": round(v[1] / tot, 4)} for k, v in pf.items()}
+        stg["enc_gemm"]["tflops"] = round(gemm_tflops, 1)
+        if pf["enc_attention"][0]:
+            stg["enc_attention"]["tflops"] = round(pf["enc_attention"][2] / (pf["enc_attention"][1] * 1e-3) / 1e12, 1)
+        if pf["logmel"][0]:
+            stg["logmel"]["GBs_algorithmic"] = round(pf["logmel"][2] / (pf["logmel"][1] * 1e-3) / 1e9, 1)
+        stg["decode"]["GBs_algorithmic"] = round(dec_gbs, 1)
+        stg["decode"]["steps_per_pass"] = steps_d / max(n_d, 1)
+        return rl, stg
+
+    roofline, stage = summarize(prof, args.steps if R == 1 else 1)
+    roofline["measured_over"] = ("the timed region" if R == 1 else
+                                 f"one uncontended calibration pass in this process (the timed region runs {R} concurrent streams, un-instrumented)")
+    steps_d, n_d = prof["decode"][2], prof["decode"][0]
+    if R > 1:      # device-level view of the timed region: algorithmic decode bytes of every pass over the wall time (encoders run in the same time)
+        roofline["timed_region_decode_bytes_over_wall_GBs"] = round(dec_bytes_per_step * (steps_d / max(n_d, 1)) * args.steps / elapsed / 1e9, 1)
 
     out = {
         "metric": "audio-sec/s (Whisper large-v3-turbo b=32) at 1/2/4/8 GPU; codec samples/s",
@@ -320,10 +373,13 @@ def main():
                                f"(T=0, timestamps, max_tokens 448, one window per clip), random-init N(0,0.02^2) weights",
                    "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "generated_tokens_per_clip_mean": float(n_gen.mean()), "decoder_steps_per_pass": steps_d / max(n_d, 1),
-                   "realtime_factor": round(value, 1)},
+                   "realtime_factor": round(value, 1), "replicas": R,
+                   "pipeline": (f"{R} model replicas on {R} HIP streams, passes dealt round-robin: the encoder of one batch overlaps the decoder of "
+                                "another; every pass is a complete log-mel + encode + decode of its 32 clips" if R > 1 else "strictly serial passes")},
         "roofline": roofline, "stages": stage,
     }
     if rank == 0 and not args.no_codec:
+        torch.cuda.set_stream(reps[0].stream)     # the codec leg times library work with torch events: same stream as the context
         out["codec"] = codec_bench(ctx, torch)
     if rank == 0 and not args.no_cpu_baseline:
         try:
@@ -336,7 +392,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    model.close()
+    for rp in reps:
+        rp.model.close()
 
 
 if __name__ == "__main__":
