@@ -237,10 +237,11 @@ def main():
         (MFMA-bound) encoder of one batch overlaps the (launch-latency-bound) decoder of another -- how one GPU is driven for
         throughput.  Every pass is still a full log-mel + encode + 448-token-budget decode of 32 clips."""
 
-        def __init__(self):
+        def __init__(self, root=None):
             self.stream = torch.cuda.Stream()
             self.ctx = m.Context(local_rank, stream=self.stream.cuda_stream)
-            self.model = HW.WhisperModel.load(self.ctx, dims, weights, dtype)
+            # the first replica uploads the weights; the others are clones: own activations / KV caches / step graph, shared weights
+            self.model = HW.WhisperModel.load(self.ctx, dims, weights, dtype) if root is None else root.model.clone(self.ctx)
             self.opts = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(self.model.special), blank_ids=[220], max_new_tokens=args.max_new_tokens)
             with torch.cuda.stream(self.stream):
                 self.tokens = torch.zeros((B, self.opts.max_tokens), dtype=torch.int32, device="cuda")
@@ -255,7 +256,8 @@ def main():
 
     R = max(1, min(args.replicas, args.steps))
     t0 = time.time()
-    reps = [Replica() for _ in range(R)]
+    reps = [Replica()]
+    reps += [Replica(reps[0]) for _ in range(R - 1)]
     del weights
     log(f"[bench] {R} replica(s) loaded in {time.time() - t0:.1f}s")
     ctx = reps[0].ctx
@@ -374,7 +376,7 @@ def main():
                    "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "generated_tokens_per_clip_mean": float(n_gen.mean()), "decoder_steps_per_pass": steps_d / max(n_d, 1),
                    "realtime_factor": round(value, 1), "replicas": R,
-                   "pipeline": (f"{R} model replicas on {R} HIP streams, passes dealt round-robin: the encoder of one batch overlaps the decoder of "
+                   "pipeline": (f"{R} model replicas (one weight copy, own activations / KV caches / step graphs) on {R} HIP streams, passes dealt round-robin: the encoder of one batch overlaps the decoder of "
                                 "another; every pass is a complete log-mel + encode + decode of its 32 clips" if R > 1 else "strictly serial passes")},
         "roofline": roofline, "stages": stage,
     }
@@ -392,7 +394,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    for rp in reps:
+    for rp in reversed(reps):                     # clones before the replica that owns the weights
         rp.model.close()
 
 

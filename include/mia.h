@@ -180,6 +180,10 @@ typedef struct {
 mia_whisper* mia_whisper_load(mia_ctx* ctx, const mia_whisper_dims* dims, const mia_tensor_view* tensors, int n_tensors,
                               int compute_dtype);
 void mia_whisper_free(mia_whisper* w);
+/* A second handle on the same (read-only) weights with its own activations, KV caches, decode state and step graph, bound to another
+ * context (= another HIP stream) of the same device -- for decoding different batches concurrently (the reference has one model per
+ * actor; this is the serving-side counterpart).  Free every clone before the handle it was cloned from. */
+mia_whisper* mia_whisper_clone(mia_whisper* src, mia_ctx* ctx);
 
 /* Replaces model.encode(mel) (WhisperDecoding.swift:98 -> AudioEncoder.swift:43-68) for a batch of 30 s windows and
  * primes the decoder's cross-attention K/V (MultiHeadAttention.swift:49-59).

@@ -62,7 +62,9 @@ struct mia_whisper {
   mia_whisper_dims dims{};
   int dtype = MIA_BF16;
   int kpad_conv1 = 0;
-  std::vector<void*> allocs;          // everything hipMalloc'ed for this model
+  std::vector<void*> allocs;          // everything hipMalloc'ed for this handle (a clone owns only its batch buffers)
+  mia_whisper* parent = nullptr;      // clone: the handle whose weights are shared (read-only)
+  int n_clones = 0;                   // live clones of this handle: it cannot be freed before them
 
   // ---- weights
   LinearW conv1, conv2;

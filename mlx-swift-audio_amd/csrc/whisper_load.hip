@@ -230,9 +230,27 @@ extern "C" mia_whisper* mia_whisper_load(mia_ctx* ctx, const mia_whisper_dims* d
 
 extern "C" void mia_whisper_free(mia_whisper* w) {
   if (!w) return;
+  if (w->n_clones > 0) { mia_fail(w->ctx, MIA_ERR_INVALID_ARGUMENT, "whisper_free: %d clone(s) still share these weights; free them first", w->n_clones); return; }
   (void)hipSetDevice(w->ctx->device);
   (void)hipStreamSynchronize(w->ctx->stream);
   if (w->step_graph) (void)hipGraphExecDestroy(w->step_graph);
   for (void* p : w->allocs) (void)hipFree(p);
+  if (w->parent) w->parent->n_clones -= 1;
   delete w;
+}
+
+// A second handle on the SAME weights with its own activations, KV caches, decode state and step graph, bound to another context
+// (HIP stream) of the same device: batches decoded on different streams then stream one weight copy (the second reader mostly hits
+// L2 / the Infinity Cache) instead of one copy each.
+extern "C" mia_whisper* mia_whisper_clone(mia_whisper* src, mia_ctx* ctx) {
+  if (!src || !ctx) return nullptr;
+  mia_whisper* root = src->parent ? src->parent : src;
+  if (ctx->device != root->ctx->device) { mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "whisper_clone: the context must be on the device that holds the weights"); return nullptr; }
+  mia_whisper* w = new mia_whisper();
+  w->ctx = ctx; w->dims = root->dims; w->dtype = root->dtype; w->kpad_conv1 = root->kpad_conv1;
+  w->conv1 = root->conv1; w->conv2 = root->conv2; w->enc_pos = root->enc_pos; w->enc = root->enc; w->ln_post = root->ln_post;
+  w->tok_emb = root->tok_emb; w->dec_pos = root->dec_pos; w->dec = root->dec; w->dec_ln = root->dec_ln;
+  w->parent = root;
+  root->n_clones += 1;
+  return w;
 }

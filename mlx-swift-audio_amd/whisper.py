@@ -158,6 +158,18 @@ class WhisperModel:
             self.ctx.lib.mia_whisper_free(self.h)
             self.h = None
 
+    def clone(self, ctx: "_lib.Context") -> "WhisperModel":
+        """A second handle on the same weights with its own batch state, bound to `ctx` (another stream of the same device)."""
+        lib = ctx.lib
+        lib.mia_whisper_clone.restype = C.c_void_p
+        lib.mia_whisper_clone.argtypes = [C.c_void_p, C.c_void_p]
+        h = lib.mia_whisper_clone(self.h, ctx.h)
+        if not h:
+            raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, lib.mia_last_error(ctx.h).decode())
+        child = WhisperModel(ctx, h, self.dims, self.dtype)
+        child._weights_owner = self          # keep the owner alive as long as the clone
+        return child
+
     def __del__(self):
         try:
             self.close()

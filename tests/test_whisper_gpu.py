@@ -264,3 +264,30 @@ def test_batch_invariance_above_one_row_tile(ctx):
     model.encode(mel[32:40])
     np.testing.assert_array_equal(model.audio_features(), feats_big[32:40])
     model.close()
+
+
+def test_clone_shares_weights_and_decodes_concurrently(ctx):
+    """mia_whisper_clone: same weights, own state, another stream -- identical results, also when both decode at the same time."""
+    import threading
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import whisper as HW
+    dims, oracle, model = _models(ctx, "micro.en", "f16", seed=5)
+    ctx2 = m.Context()
+    twin = model.clone(ctx2)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    o = HW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=14)
+    mel_a, mel_b = _mel(dims, 4, 31, "f16"), _mel(dims, 3, 32, "f16")
+    want_a = HW.GreedyDecoder(model, o).decode(mel_a)
+    want_b = HW.GreedyDecoder(model, o).decode(mel_b)
+    got = {}
+    ths = [threading.Thread(target=lambda: got.__setitem__("a", HW.GreedyDecoder(model, o).decode(mel_a))),
+           threading.Thread(target=lambda: got.__setitem__("b", HW.GreedyDecoder(twin, o).decode(mel_b)))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for x, y in zip(got["a"] + got["b"], want_a + want_b):
+        assert x.tokens == y.tokens
+    twin.close()
+    ctx2.close()
+    model.close()
