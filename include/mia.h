@@ -125,6 +125,11 @@ int mia_op_conv1d_f32(mia_ctx* ctx, const float* x, int64_t ldx, int T_in, const
 int mia_dequant_affine(mia_ctx* ctx, const uint32_t* wq, const void* scales, const void* biases, int64_t rows, int64_t cols,
                        int group_size, int bits, int scale_dtype, void* out, int out_dtype, int mem);
 
+/* fp32 scaled-dot-product attention, head dim 64, unmasked, DEVICE pointers (MLXFast.scaledDotProductAttention as called at
+ * Codec/S3Gen/Matcha/MatchaTransformer.swift:58-66): q / k / v float32 [B*T][ld*] with head h in columns h*64 .. h*64+63. */
+int mia_op_attention_f32(mia_ctx* ctx, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out,
+                         int64_t ldo, int B, int T, int H, float scale);
+
 /* ---- Whisper ---------------------------------------------------------------------------------- */
 /* Model dimensions == ModelDimensions (STT/Whisper/Config/WhisperConfig.swift:9-86), read by the caller
  * from config.json. */

@@ -7,7 +7,9 @@
 // term is one more 64-wide contraction against per-position keys: the POS variant runs the QK product over the concatenated
 // 128-wide operands [q + u | q + v] . [k | p].
 //
-// One 256-thread workgroup = 64 queries of one (batch, head): 2 query groups of 32 x 2 halves of the key range (split-KV).  S^T = K Q^T on v_mfma_f32_32x32x2_f32, so
+// One 256-thread workgroup = 32 queries of one (batch, head), its 4 waves each walking a quarter of the key tiles (split-KV, merged
+// through LDS in wave order).  Work units are small on purpose: with 64- or 128-query workgroups T = 1050 gave 272 / 144 workgroups for 256
+// CUs and the kernel time was set by the CUs holding two of them (measured 90 us at T = 1050 vs 30 us at T = 525).  S^T = K Q^T on v_mfma_f32_32x32x2_f32, so
 // a lane owns ONE query column and 16 keys of it: the online softmax is in-lane plus one cross-half shuffle, and the S^T
 // accumulator registers are, in order, the B operand of O^T += V^T P^T (the A operand reads V rows in the matching key order).
 // K / P / V tiles of 32 keys are staged HBM -> registers -> LDS with row strides (66 | 130, 72 floats) that make every
@@ -22,34 +24,44 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
   constexpr int DQK = POS ? 128 : 64;
   constexpr int SK = DQK + 2;       // K row stride (floats): 2*key + half distinct mod 64
   constexpr int SV = 72;            // V row stride: keys k and k+4 land 32 banks apart
-  // two KV tiles per iteration: waves 0,1 (query groups 0,1) walk the even tiles, waves 2,3 the odd ones (split-KV inside the
-  // workgroup: the per-wave chain of dependent MFMAs -- the latency that bounds this kernel -- is halved); merged through LDS.
-  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * SK + 2 * 32 * SV];   // K tiles | V tiles; reused for the final merge
+  // four KV tiles per iteration, one per wave
+  constexpr int NKV = 4;
+  __shared__ __attribute__((aligned(16))) float lds[NKV * 32 * SK + NKV * 32 * SV];   // K tiles | V tiles; reused for the Q tile and the merge
   float (*Ks)[32 * SK] = reinterpret_cast<float (*)[32 * SK]>(lds);
-  float (*Vs)[32 * SV] = reinterpret_cast<float (*)[32 * SV]>(lds + 2 * 32 * SK);
-  static_assert(2 * 64 * 34 <= 2 * 32 * SK + 2 * 32 * SV, "merge buffer must fit in the tile storage");
+  float (*Vs)[32 * SV] = reinterpret_cast<float (*)[32 * SV]>(lds + NKV * 32 * SK);
+  static_assert((NKV - 1) * 64 * 34 <= NKV * 32 * SK + NKV * 32 * SV, "merge buffer must fit in the tile storage");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qg = wave & 1, kvh = wave >> 1;
+  const int kvh = wave;
   const int lq = lane & 31, lh = lane >> 5;
-  const int nqb = (a.T + 63) / 64;
+  const int nqb = (a.T + 31) / 32;
   const int qb = blockIdx.x % nqb, hb = blockIdx.x / nqb;
   const int h = hb % a.H, b = hb / a.H;
-  const int q0 = qb * 64 + qg * 32;
+  const int q0 = qb * 32;
   const float* Q = a.q + (int64_t)b * a.T * a.ldq + h * 64;
   const float* K = a.k + (int64_t)b * a.T * a.ldk + h * 64;
   const float* V = a.v + (int64_t)b * a.T * a.ldv + h * 64;
   const float* P = POS ? a.p + h * 64 : nullptr;
 
-  // ---- Q^T fragments: lane holds (q + bias)[2 i + lh] * scale * log2(e), i = 0..31 (and the +v copy for POS)
+  // ---- Q^T fragments: lane holds (q + bias)[2 i + lh] * scale * log2(e), i = 0..31 (and the +v copy for POS).  The 64 x 64 query tile is
+  // first read coalesced (float4 per thread) into LDS -- per-lane strided 8-byte reads of 32 different rows serialised in the TA.
   float qf[DQK / 2];
   {
-    int q = q0 + lq; q = q < a.T ? q : a.T - 1;
-    const float* qp = Q + (int64_t)q * a.ldq;
+    float* Qs = lds;                                   // [32][66], dead before the first K / V tile is written
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (tid >> 4) + 16 * j, c4 = (tid & 15) * 4;
+      int q = q0 + row; q = q < a.T ? q : a.T - 1;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Q + (int64_t)q * a.ldq + c4);
+      float* d = Qs + row * 66 + c4;
+      *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
+    }
+    __syncthreads();
+    const float* qp = Qs + lq * 66 + lh;
     const float sc = a.scale * 1.4426950408889634f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-      const float2 v2 = *reinterpret_cast<const float2*>(qp + 2 * i);
-      const float x = lh ? v2.y : v2.x;
+      const float x = qp[2 * i];
       if (POS) {
         qf[i] = (x + a.bias_u[h * 64 + 2 * i + lh]) * sc;
         qf[32 + i] = (x + a.bias_v[h * 64 + 2 * i + lh]) * sc;
@@ -59,13 +71,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     }
   }
 
-  // ---- staging: 2 tiles x 32 keys x 64 floats = 1024 float4 per source, 4 per thread: thread -> (tile = tid >> 7, row pair, 16-B column)
-  const int s_tile = tid >> 7, s_row = (tid & 127) >> 4, s_c4 = (tid & 15) * 4;      // rows s_row + 8 j, j = 0..3
-  f32x4 rk[4], rp[4], rv[4];       // native vectors: HIP's float4 struct copies were lowered to memcpy through a scratch array
+  // ---- staging: 4 tiles x 32 keys x 64 floats = 2048 float4 per source, 8 per thread: thread -> (tile = tid >> 6, rows (tid & 63) >> 4 + 4 j, 16-B column)
+  constexpr int NST = 8;
+  const int s_tile = tid >> 6, s_row = (tid & 63) >> 4, s_c4 = (tid & 15) * 4;
+  f32x4 rk[NST], rp[NST], rv[NST];   // native vectors: HIP's float4 struct copies were lowered to memcpy through a scratch array
   auto load_regs = [&](int key0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int key = key0 + 32 * s_tile + s_row + 8 * j; key = key < a.T ? key : a.T - 1;
+    for (int j = 0; j < NST; ++j) {
+      int key = key0 + 32 * s_tile + s_row + 4 * j; key = key < a.T ? key : a.T - 1;
       rk[j] = *reinterpret_cast<const f32x4*>(K + (int64_t)key * a.ldk + s_c4);
       rv[j] = *reinterpret_cast<const f32x4*>(V + (int64_t)key * a.ldv + s_c4);
       if (POS) rp[j] = *reinterpret_cast<const f32x4*>(P + (int64_t)key * a.ldp + s_c4);
@@ -73,8 +86,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
   };
   auto write_lds = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = s_row + 8 * j;
+    for (int j = 0; j < NST; ++j) {
+      const int row = s_row + 4 * j;
       float* kd = Ks[s_tile] + row * SK + s_c4;              // rows are 8-byte aligned only
       *reinterpret_cast<float2*>(kd) = make_float2(rk[j][0], rk[j][1]);
       *reinterpret_cast<float2*>(kd + 2) = make_float2(rk[j][2], rk[j][3]);
@@ -93,14 +106,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     for (int r = 0; r < 16; ++r) acc_o[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int npairs = (a.T + 63) / 64;
+  const int npairs = (a.T + 32 * NKV - 1) / (32 * NKV);
   load_regs(0);
   for (int kp = 0; kp < npairs; ++kp) {
-    const int key0 = kp * 64 + 32 * kvh;          // this wave's tile
+    const int key0 = kp * 32 * NKV + 32 * kvh;    // this wave's tile
     __syncthreads();                              // previous tiles fully consumed
     write_lds();
     __syncthreads();
-    if (kp + 1 < npairs) load_regs((kp + 1) * 64);
+    if (kp + 1 < npairs) load_regs((kp + 1) * 32 * NKV);
     if (key0 < a.T) {                             // (the odd tail tile may be absent: wave-uniform)
 
     // ---- S^T = K Q^T
@@ -182,11 +195,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     }
   }
 
-  // ---- merge the two KV halves (fixed order: even tiles' state + odd tiles' state), normalise, store
+  // ---- merge the four KV quarters in wave order (fixed order: deterministic), normalise, store
   l_run += __shfl_xor(l_run, 32, 64);             // row sum over this wave's keys, in both lane halves
-  __syncthreads();                                // K / V tiles are dead: reuse Ks as the hand-over buffer
-  float* mb = lds + (qg * 64 + lane) * 34;        // [2 groups][64 lanes][m, l, 32 x o]
-  if (kvh == 1) {
+  __syncthreads();                                // K / V tiles are dead: reuse the storage as the hand-over buffer
+  if (kvh > 0) {
+    float* mb = lds + ((kvh - 1) * 64 + lane) * 34;   // [3 waves][64 lanes][m, l, 32 x o]
     mb[0] = m_run; mb[1] = l_run;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -194,24 +207,38 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
       for (int r = 0; r < 16; ++r) mb[2 + db * 16 + r] = acc_o[db][r];
   }
   __syncthreads();
-  if (kvh == 1) return;
+  if (kvh > 0) return;
   {
-    const float m1 = mb[0], l1 = mb[1];
-    const float m = fmaxf(m_run, m1);
-    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
-    const float inv = 1.0f / (l_run * a0 + l1 * a1);
+    float m = m_run;
+#pragma unroll
+    for (int w2 = 0; w2 < NKV - 1; ++w2) m = fmaxf(m, lds[(w2 * 64 + lane) * 34]);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m);
+    float den = l_run * a0;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[db][r] *= a0;
+#pragma unroll
+    for (int w2 = 0; w2 < NKV - 1; ++w2) {
+      const float* mb = lds + (w2 * 64 + lane) * 34;
+      const float mw = mb[0];
+      const float aw = mw == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw - m);
+      den += mb[1] * aw;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] += mb[2 + db * 16 + r] * aw;
+    }
+    const float inv = 1.0f / den;
     const int q = q0 + lq;
     if (q < a.T) {
       float* op = a.out + ((int64_t)b * a.T + q) * a.ldo + h * 64 + 4 * lh;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (acc_o[db][4 * g + e] * a0 + mb[2 + db * 16 + 4 * g + e] * a1) * inv;
-          *reinterpret_cast<float4*>(op + db * 32 + 8 * g) = make_float4(o[0], o[1], o[2], o[3]);
-        }
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(op + db * 32 + 8 * g) =
+              make_float4(acc_o[db][4 * g] * inv, acc_o[db][4 * g + 1] * inv, acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv);
     }
   }
 }
@@ -228,7 +255,7 @@ const char* mia_attn_f32_check(const AttnF32Args& a) {
 }
 
 int mia_attn_f32_launch(const AttnF32Args& a, hipStream_t s) {
-  dim3 grid(((a.T + 63) / 64) * a.H * a.B), block(256);
+  dim3 grid(((a.T + 31) / 32) * a.H * a.B), block(256);
   if (a.p) hipLaunchKernelGGL(attn_f32_kernel<true>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(attn_f32_kernel<false>, grid, block, 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -50,3 +50,16 @@ extern "C" int mia_op_conv1d_f32(mia_ctx* ctx, const float* x, int64_t ldx, int 
   if (codec_conv_gemm_launch(g, 1, ctx->stream)) return mia_fail(ctx, MIA_ERR_DEVICE, "op_conv1d_f32: launch failed");
   return MIA_OK;
 }
+
+// fp32 scaled-dot-product attention, head dim 64, full (unmasked) softmax; device pointers (MLXFast.scaledDotProductAttention as used by
+// Codec/S3Gen/Matcha/MatchaTransformer.swift:58-66): q/k/v [B*T][ld] with head h in columns h*64.., out [B*T][ldo].
+extern "C" int mia_op_attention_f32(mia_ctx* ctx, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out,
+                                    int64_t ldo, int B, int T, int H, float scale) {
+  if (!ctx) return MIA_ERR_INVALID_ARGUMENT;
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  AttnF32Args a;
+  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo; a.B = B; a.T = T; a.H = H; a.scale = scale;
+  if (const char* e = mia_attn_f32_check(a)) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
+  if (mia_attn_f32_launch(a, ctx->stream)) return mia_fail(ctx, MIA_ERR_DEVICE, "op_attention_f32: launch failed");
+  return MIA_OK;
+}
