@@ -38,7 +38,10 @@ template <int WM, int WN, int KC>
 __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   constexpr int GBM = 64 * WM;
   constexpr int GBN = 64 * WN;
-  constexpr int GBK = 32 * KC, GSTR = GBK + 1;   // LDS row stride odd: conflict-free column reads
+  // LDS rows hold the K-tile PERMUTED: even k in the first half, odd k in the second.  v_mfma_f32_32x32x2_f32 wants k = 2 s + (lane >> 5)
+  // for step s, so a lane's operands of 4 consecutive steps are 4 consecutive floats of "its" half: one ds_read_b128 per 4 MFMA steps
+  // instead of four ds_read_b32 (the kernel's rate tracked the number of LDS operand reads per MFMA, not the MFMA count).
+  constexpr int GBK = 32 * KC, GH = GBK / 2, GSTR = GBK + 4;   // row stride 16-byte aligned; 36 floats: 8 consecutive rows hit distinct 16-B slots
   __shared__ float As[GBM * GSTR];
   __shared__ float Bs[GBN * GSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,15 +108,17 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
           v.z = v.z > 0.f ? v.z : v.z * g.lrelu_slope; v.w = v.w > 0.f ? v.w : v.w * g.lrelu_slope;
         }
         if (!((amask >> (ch * 8 + i)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        float* d = As + (s_row + 32 * i) * GSTR + 32 * ch + s_col;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        float* d = As + (s_row + 32 * i) * GSTR + (32 * ch + s_col) / 2;
+        *reinterpret_cast<float2*>(d) = make_float2(v.x, v.z);            // even k
+        *reinterpret_cast<float2*>(d + GH) = make_float2(v.y, v.w);       // odd k
       }
 #pragma unroll
       for (int i = 0; i < 2 * WN; ++i) {
         float4 v = rb[ch][i];
         if (!((bmask >> (ch * 8 + i)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        float* d = Bs + (s_row + 32 * i) * GSTR + 32 * ch + s_col;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        float* d = Bs + (s_row + 32 * i) * GSTR + (32 * ch + s_col) / 2;
+        *reinterpret_cast<float2*>(d) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2*>(d + GH) = make_float2(v.y, v.w);
       }
     }
   };
@@ -126,8 +131,8 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int a_off = (wr * 32 * WM + (lane & 31)) * GSTR + (lane >> 5);
-  const int b_off = (wc * 32 * WN + (lane & 31)) * GSTR + (lane >> 5);
+  const int a_off = (wr * 32 * WM + (lane & 31)) * GSTR + (lane >> 5) * GH;
+  const int b_off = (wc * 32 * WN + (lane & 31)) * GSTR + (lane >> 5) * GH;
   const int nk = (Ktot + GBK - 1) / GBK;
   load_tiles(0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -139,15 +144,12 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
     // the compiler every MFMA waited on the ds_read issued just before it (~120 cycles of LDS latency per 64-cycle MFMA: measured
     // 2.1x the MFMA bound per K-tile).
     constexpr int NS = GBK / 2, PB = 4;
-    float fa[2][PB][WM], fb[2][PB][WN];
+    f32x4 fa[2][WM], fb[2][WN];                  // one 128-bit read = the operands of PB = 4 consecutive MFMA steps
     auto lds_batch = [&](int buf, int s0) {
 #pragma unroll
-      for (int u = 0; u < PB; ++u) {
+      for (int i = 0; i < WM; ++i) fa[buf][i] = *reinterpret_cast<const f32x4*>(As + a_off + i * 32 * GSTR + s0);
 #pragma unroll
-        for (int i = 0; i < WM; ++i) fa[buf][u][i] = As[a_off + i * 32 * GSTR + 2 * (s0 + u)];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) fb[buf][u][j] = Bs[b_off + j * 32 * GSTR + 2 * (s0 + u)];
-      }
+      for (int j = 0; j < WN; ++j) fb[buf][j] = *reinterpret_cast<const f32x4*>(Bs + b_off + j * 32 * GSTR + s0);
     };
     lds_batch(0, 0);
 #pragma unroll
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u][i], fb[cur][u][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][u], fb[cur][j][u], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
