@@ -103,11 +103,17 @@ __global__ __launch_bounds__(256) void dec_reduce_ln(const float* __restrict__ p
       const f32x4 bs = *reinterpret_cast<const f32x4*>(bias + 4 * c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[j] += bs[j];
-      for (int k = 0; k < S; ++k) {
-        const f32x4 pv = *reinterpret_cast<const f32x4*>(partial + ((int64_t)k * B + b) * D + 4 * c);
+      // split-K slices come from other XCDs (L2 misses): issue every load before the first add.  S <= 4; a slot k >= S
+      // re-reads slice S-1 and is dropped, so the loads are unconditional and the sum keeps its fixed order.
+      f32x4 pv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] += pv[j];
-      }
+      for (int k = 0; k < 4; ++k) pv[k] = *reinterpret_cast<const f32x4*>(partial + ((int64_t)(k < S ? k : S - 1) * B + b) * D + 4 * c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < S) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] += pv[k][j];
+        }
       v[i] = a;
       *reinterpret_cast<f32x4*>(xr + 4 * c) = a;
     } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -18,8 +18,11 @@
 #include <vector>
 
 #include "decode.h"
+#include "gemm.h"
 
-struct LmState { int pos; int n_hist; int finished; int n_gen; int n_embeds; int n_out; int u_cursor; int pad; };
+struct LmState { int pos; int n_hist; int finished; int n_gen; int n_embeds; int n_out; int u_cursor; int n_prompt; };
+
+struct RasParams { float top_p; int top_k; int win; float tau; int eos; int min_len; int max_len; int n_uniforms; };
 
 struct LmLayer {
   float* in_norm = nullptr; float* post_norm = nullptr;
@@ -54,11 +57,13 @@ struct mia_lm {
   float* uniforms = nullptr;    // [max_ctx]
   uint32_t* hist_bins = nullptr;  // sampler scratch
   LmState* state = nullptr;
-  hipGraphExec_t graph = nullptr;
+  hipGraphExec_t graph = nullptr;       // one decode step (forward / top-p sampler / RAS sampler), re-captured when its sampler arguments change
+  int graph_mode = -1;                  // 0 forward, 1 top-p, 2 RAS
   mia_lm_sampler graph_sampler{};
-  bool graph_valid = false;
-  bool graph_sampling = false;
+  RasParams graph_ras{};
   int S_qkv = 1, S_o = 1, S_down = 1;
+  // batched prompt pass (lm_prefill): row buffers for one chunk of PF_ROWS positions, allocated on first use
+  char* pf_buf = nullptr;
 };
 
 namespace {
@@ -90,13 +95,15 @@ __device__ __forceinline__ void rms_store(const f32x4 (&v)[LM_NV], int nv, int D
 }
 
 // x = E[token[pos]] (or a caller-provided embedding row);  h = RMSNorm(x) * w
+// One workgroup per row.  The step graph runs one row at st->pos (pos0 < 0); the batched prompt pass runs rows pos0 + blockIdx.x.
 template <typename T>
 __global__ __launch_bounds__(256) void lm_embed_norm(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ emb, const uint16_t* __restrict__ gen_emb,
                                                      const float* __restrict__ embeds, const float* __restrict__ w,
-                                                     float* __restrict__ x, uint16_t* __restrict__ h, const LmState* __restrict__ st, int D, float eps) {
+                                                     float* __restrict__ x, uint16_t* __restrict__ h, const LmState* __restrict__ st, int D, float eps, int pos0) {
   __shared__ float sh[4];
   const int tid = threadIdx.x, nv = D >> 2;
-  const int pos = st->pos;
+  const int pos = (pos0 < 0 ? st->pos : pos0) + (int)blockIdx.x;
+  x += (int64_t)blockIdx.x * D; h += (int64_t)blockIdx.x * D;
   const bool from_rows = pos < st->n_embeds;               // prompt given as embedding rows
   const int tok = from_rows ? 0 : tokens[pos];
   const uint16_t* e = ((st->n_embeds > 0 && gen_emb) ? gen_emb : emb) + (int64_t)tok * D;
@@ -118,23 +125,30 @@ __global__ __launch_bounds__(256) void lm_embed_norm(const int32_t* __restrict__
   rms_store<T>(v, nv, D, eps, w, h, sh);
 }
 
-// x += sum_s partial[s];  h = RMSNorm(x) * w
+// x += sum_s partial[s];  h = RMSNorm(x) * w        (one workgroup per row; the batched prompt pass runs it with S = 0)
 template <typename T>
 __global__ __launch_bounds__(256) void lm_reduce_norm(const float* __restrict__ partial, int S, const float* __restrict__ w, float* __restrict__ x,
                                                       uint16_t* __restrict__ h, int D, float eps) {
   __shared__ float sh[4];
   const int tid = threadIdx.x, nv = D >> 2;
+  x += (int64_t)blockIdx.x * D; h += (int64_t)blockIdx.x * D;
   f32x4 v[LM_NV];
 #pragma unroll
   for (int i = 0; i < LM_NV; ++i) {
     const int c = tid + 256 * i;
     if (c < nv) {
       f32x4 a = *reinterpret_cast<const f32x4*>(x + 4 * c);
-      for (int k = 0; k < S; ++k) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(partial + (int64_t)k * D + 4 * c);
+      // the slices were written by other XCDs (L2 misses): issue all loads before the first add.  S <= 8; slot k >= S re-reads
+      // slice S-1 and is discarded, so the loads are unconditional and the sum keeps its fixed order.
+      f32x4 p[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] += p[j];
-      }
+      for (int k = 0; k < 8; ++k) p[k] = S > 0 ? *reinterpret_cast<const f32x4*>(partial + (int64_t)(k < S ? k : S - 1) * D + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < S) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] += p[k][j];
+        }
       v[i] = a;
       *reinterpret_cast<f32x4*>(x + 4 * c) = a;
     } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -143,17 +157,26 @@ __global__ __launch_bounds__(256) void lm_reduce_norm(const float* __restrict__ 
 }
 
 // q|k|v = sum_s partial[s] + bias; RoPE (split-half pairs (i, i+dh/2), angle = pos * inv_freq[i]) on q and k; q -> qout,
-// k, v -> cache[kv head][pos][:]          one thread per rotation pair / per v element
+// k, v -> cache[kv head][pos][:]          one thread per rotation pair / per v element; blockIdx.y = row of the batched prompt pass
 template <typename T>
 __global__ __launch_bounds__(256) void lm_rope_cache(const float* __restrict__ part, int S, const float* __restrict__ bias, const float* __restrict__ inv_freq,
                                                      uint16_t* __restrict__ qout, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
-                                                     const LmState* __restrict__ st, int Hq, int Hkv, int dh, int max_ctx) {
+                                                     const LmState* __restrict__ st, int Hq, int Hkv, int dh, int max_ctx, int pos0) {
   const int Nq = Hq * dh, Nk = Hkv * dh, N = Nq + 2 * Nk;
   const int half = dh >> 1;
-  const int pos = st->pos;
+  const int pos = (pos0 < 0 ? st->pos : pos0) + (int)blockIdx.y;
+  part += (int64_t)blockIdx.y * N; qout += (int64_t)blockIdx.y * Nq;      // prompt pass: S == 1, one GEMM output row per position
   const int n_pairs = (Hq + Hkv) * half;
   const int e = blockIdx.x * 256 + threadIdx.x;
-  auto val = [&](int n) { float a = bias ? bias[n] : 0.f; for (int k = 0; k < S; ++k) a += part[(int64_t)k * N + n]; return a; };
+  auto val = [&](int n) {        // S <= 4 slices, loads issued together (see lm_reduce_norm)
+    float p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = part[(int64_t)(k < S ? k : S - 1) * N + n];
+    float a = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < S) a += p[k];
+    return a;
+  };
   if (e < n_pairs) {
     const int head = e / half, i = e - head * half;       // head < Hq: query head, else key head
     const int base = head * dh;                           // q and k sections are contiguous: [q heads | k heads]
@@ -172,18 +195,23 @@ __global__ __launch_bounds__(256) void lm_rope_cache(const float* __restrict__ p
   }
 }
 
-// grouped-query single-token attention: one workgroup per query head; DH/8 lanes share a key
+// grouped-query single-token attention: one workgroup per (query head, row); DH/8 lanes share a key.  Row r of the batched
+// prompt pass sits at position pos0 + r and sees keys [0, pos0 + r] -- causal by construction, same arithmetic as a decode step.
+// 16 waves per workgroup: a decode step has only n_heads workgroups, so the key loop's memory latency is hidden by waves of
+// the same workgroup (4 waves: +12 us per layer per 300 keys on Orpheus-3B; 16 waves: a quarter of that).
+constexpr int ATT_NW = 16;
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void lm_attention(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
-                                                    uint16_t* __restrict__ out, const LmState* __restrict__ st, int Hq, int Hkv, int max_ctx, float scale) {
-  extern __shared__ float sc[];            // [max_ctx] scores, then red[4][DH] + red2[8]
+__global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+                                                    uint16_t* __restrict__ out, const LmState* __restrict__ st, int Hq, int Hkv, int max_ctx, float scale, int pos0) {
+  extern __shared__ float sc[];            // [max_ctx] scores, then red[ATT_NW][DH] + red2[2 * ATT_NW]
   constexpr int LPK = DH / 8;              // lanes per key
   constexpr int KPW = 64 / LPK;            // keys per wave instruction
   float* red = sc + max_ctx;
-  float* red2 = red + 4 * DH;
+  float* red2 = red + ATT_NW * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, kvh = h / (Hq / Hkv);
-  const int nk = st->pos + 1;
+  const int nk = (pos0 < 0 ? st->pos : pos0) + (int)blockIdx.y + 1;
+  q += (int64_t)blockIdx.y * Hq * DH; out += (int64_t)blockIdx.y * Hq * DH;
   const int c = lane % LPK, g = lane / LPK;
   const uint16_t* kb = kc + (int64_t)kvh * max_ctx * DH;
   const uint16_t* vb = vc + (int64_t)kvh * max_ctx * DH;
@@ -193,7 +221,7 @@ __global__ __launch_bounds__(256) void lm_attention(const uint16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = T::to_f32((uint16_t)qv[j]);
   }
-  for (int k0 = wave * KPW * 4; k0 < nk; k0 += 4 * KPW * 4) {
+  for (int k0 = wave * KPW * 4; k0 < nk; k0 += ATT_NW * KPW * 4) {
     s16x8 kv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { int key = k0 + KPW * u + g; key = key < nk ? key : nk - 1; kv[u] = *reinterpret_cast<const s16x8*>(kb + (int64_t)key * DH + c * 8); }
@@ -210,21 +238,25 @@ __global__ __launch_bounds__(256) void lm_attention(const uint16_t* __restrict__
   }
   __syncthreads();
   float m = -INFINITY;
-  for (int i = tid; i < nk; i += 256) m = fmaxf(m, sc[i]);
+  for (int i = tid; i < nk; i += 64 * ATT_NW) m = fmaxf(m, sc[i]);
   m = wave_max(m);
   if (lane == 0) red2[wave] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red2[0], red2[1]), fmaxf(red2[2], red2[3]));
+  m = red2[0];
+#pragma unroll
+  for (int i = 1; i < ATT_NW; ++i) m = fmaxf(m, red2[i]);
   float sum = 0.f;
-  for (int i = tid; i < nk; i += 256) { const float p = __expf(sc[i] - m); sc[i] = p; sum += p; }
+  for (int i = tid; i < nk; i += 64 * ATT_NW) { const float p = __expf(sc[i] - m); sc[i] = p; sum += p; }
   sum = wave_sum(sum);
-  if (lane == 0) red2[4 + wave] = sum;
+  if (lane == 0) red2[ATT_NW + wave] = sum;
   __syncthreads();
-  sum = (red2[4] + red2[5]) + (red2[6] + red2[7]);
+  sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < ATT_NW; ++i) sum += red2[ATT_NW + i];
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int k0 = wave * KPW * 4; k0 < nk; k0 += 4 * KPW * 4) {
+  for (int k0 = wave * KPW * 4; k0 < nk; k0 += ATT_NW * KPW * 4) {
     s16x8 vv[4]; float pw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -246,7 +278,12 @@ __global__ __launch_bounds__(256) void lm_attention(const uint16_t* __restrict__
     for (int j = 0; j < 8; ++j) red[wave * DH + c * 8 + j] = acc[j];
   }
   __syncthreads();
-  if (tid < DH) out[h * DH + tid] = T::from_f32(((red[tid] + red[DH + tid]) + (red[2 * DH + tid] + red[3 * DH + tid])) / sum);
+  if (tid < DH) {
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < ATT_NW; ++i) o += red[i * DH + tid];
+    out[h * DH + tid] = T::from_f32(o / sum);
+  }
 }
 
 // ---- sampler: repetition penalty -> temperature -> top-p (keep the first token that crosses p) -> inverse-CDF draw ----
@@ -272,13 +309,54 @@ __device__ __forceinline__ float blk1024_max(float v, float* sh) {
   return r;
 }
 
+// Level histograms of the radix select live in LDS.  Measured on gfx950 (tools/micro/lds_atomic_rate.hip, 1024 threads): ds_add_f32 to
+// lane-distinct words runs at 0.8 lane-ops/ns, ds_add_u32 at 37, ds_add_u64 at 25 -- float LDS atomics are ~40x slower than integer
+// ones, and 157 k of them cost 200 us.  So a bin holds ONE u64: (count << 44) | sum of the bits below the level's digit.  Every p of
+// a bin shares sign and exponent (the top level's digit IS sign|exponent), so p = base + low * ulp and the bin's sum is exactly
+// count * base + ulp * sum(low): integer atomics, order-independent, exact.  Copies per lane group keep a wave whose lanes all hit
+// one bin (the usual case at the top level) from serialising: 64 copies x 128 bins at the top (p <= 1 -> exponent field <= 127).
+constexpr int SMP_W[3] = {9, 12, 11};                 // digit widths, top down: sign|exponent, 12 mantissa bits, 11 mantissa bits
+constexpr int SMP_SH[3] = {23, 11, 0};
+constexpr int SMP_NB[3] = {128, 4096, 2048};
+constexpr int SMP_CP[3] = {64, 4, 8};                 // copies
+constexpr int SMP_ST[3] = {129, 4096 + 4, 2048 + 4};  // copy stride in u64 words (skews equal bins across banks)
+constexpr size_t SMP_LDS_BYTES = (size_t)4 * (4096 + 4) * 8;              // 131 200 B, the largest level
+constexpr int SMP_CNT_SHIFT = 44;                     // V < 2^20 tokens, 23-bit `low`: 43 bits of sum
+
+template <typename V>
+__device__ __forceinline__ V wave_incl_scan(V v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const V t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+  return v;
+}
+// exclusive prefix over the 1024 threads of the workgroup (thread order); sh: 16 floats/ints of scratch
+template <typename V>
+__device__ __forceinline__ V blk1024_excl_scan(V v, V* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const V incl = wave_incl_scan(v, lane);
+  V excl = __shfl_up(incl, 1, 64);
+  if (lane == 0) excl = (V)0;
+  __syncthreads();
+  if (lane == 63) sh[wave] = incl;
+  __syncthreads();
+  V base = (V)0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) if (i < wave) base += sh[i];
+  return base + excl;
+}
+
 __global__ __launch_bounds__(1024) void lm_sample(float* __restrict__ logits, int V, int32_t* __restrict__ tokens, int32_t* __restrict__ hist,
-                                                  const float* __restrict__ uniforms, LmState* __restrict__ st, mia_lm_sampler sp, int n_prompt, int max_ctx) {
+                                                  const float* __restrict__ uniforms, LmState* __restrict__ st, mia_lm_sampler sp, int n_prompt_arg, int max_ctx) {
+  const int n_prompt = n_prompt_arg < 0 ? st->n_prompt : n_prompt_arg;      // the step graph reads it from the state: one graph serves every prompt length
+  extern __shared__ unsigned long long hbin[];                               // per-copy bins, layout per level (see above)
+  __shared__ double shd[16];
+  __shared__ double s_d[2];
   __shared__ float sh[16];
-  __shared__ float hsum[2048];
-  __shared__ unsigned hcnt[2048];
+  __shared__ int shi[16];
   __shared__ float s_f[4];
-  __shared__ int s_i[4];
+  __shared__ int s_i[6];
+  __shared__ float wtot[16];
+  __shared__ int wtie[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pos = st->pos;
   const int cur_len = pos + 1;
@@ -297,152 +375,226 @@ __global__ __launch_bounds__(1024) void lm_sample(float* __restrict__ logits, in
     __syncthreads();
   }
   const float inv_t = 1.0f / fmaxf(sp.temperature, 1e-6f);
-  // 2. softmax statistics of the temperature-scaled logits
+  const int nv4 = V >> 2, tail0 = nv4 << 2;            // float4 body + scalar tail
+  f32x4* l4 = reinterpret_cast<f32x4*>(logits);
+  // 2. softmax statistics of the temperature-scaled logits; the unnormalised probabilities p = exp(z - max) REPLACE the logits
+  //    (the buffer is rewritten by the next step's head GEMM), so every later pass reads the same p without another exp
   float mx = -INFINITY;
-  for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, logits[i] * inv_t);
+  for (int i = tid; i < nv4; i += 8192) {              // the logits were written by other XCDs: eight 16-byte misses in flight per lane
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int k = i + 1024 * u; v[u] = l4[k < nv4 ? k : i]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mx = fmaxf(fmaxf(mx, fmaxf(v[u][0], v[u][1]) * inv_t), fmaxf(v[u][2], v[u][3]) * inv_t);
+  }
+  if (tail0 + tid < V) mx = fmaxf(mx, logits[tail0 + tid] * inv_t);
   mx = blk1024_max(mx, sh);
   float tot = 0.f;
-  for (int i = tid; i < V; i += 1024) tot += __expf(logits[i] * inv_t - mx);
-  tot = blk1024_sum(tot, sh);
-  // 3. top-p: find the bit pattern of the smallest kept (unnormalised) probability
+  for (int i = tid; i < nv4; i += 4096) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int k = i + 1024 * u; v[u] = l4[k < nv4 ? k : i]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + 1024 * u < nv4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[u][j] = __expf(v[u][j] * inv_t - mx);
+        l4[i + 1024 * u] = v[u];
+        tot += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+      }
+  }
+  if (tail0 + tid < V) { const float p = __expf(logits[tail0 + tid] * inv_t - mx); logits[tail0 + tid] = p; tot += p; }
+  tot = blk1024_sum(tot, sh);                          // (its barriers also publish the p stores to the whole workgroup)
+  const float* __restrict__ P = logits;
+  const f32x4* __restrict__ P4 = reinterpret_cast<const f32x4*>(logits);
+  // 3. top-p: find the bit pattern of the smallest kept probability by a 3-level radix select (11 | 11 | 10 bits, top down)
   unsigned thr_bits = 0u;        // keep p > thr, plus `keep_ties` of the p == thr (lowest index first)
   int keep_ties = 0x7fffffff;
-  float kept_sum = tot;
   const bool use_top_p = sp.top_p > 0.0f && sp.top_p < 1.0f && V > 1;
   if (use_top_p) {
-    const float target = sp.top_p * tot;              // cumulative (descending) sum must EXCEED this
+    const double target = (double)(sp.top_p * tot);   // cumulative (descending) sum must EXCEED this
     unsigned prefix = 0u, mask = 0u;                  // bits fixed so far
-    float cum_above = 0.f;                            // sum of probabilities strictly above the current candidate range
-    const int shifts[3] = {21, 10, 0};
-    const int widths[3] = {11, 11, 10};
+    double cum_above = 0.0;                           // sum of probabilities strictly above the current candidate range
+#pragma unroll 1
     for (int lvl = 0; lvl < 3; ++lvl) {
-      for (int i = tid; i < 2048; i += 1024) { hsum[i] = 0.f; hcnt[i] = 0u; }
+      constexpr unsigned long long ONE = 1ull << SMP_CNT_SHIFT;
+      const int shf = SMP_SH[lvl], nb = SMP_NB[lvl], n_copies = SMP_CP[lvl], stride = SMP_ST[lvl];
+      const unsigned dmask = (1u << SMP_W[lvl]) - 1u, lmask = (1u << shf) - 1u;
+      const int cpy = (lane & (n_copies - 1)) * stride;
+      for (int i = tid; i < n_copies * stride; i += 1024) hbin[i] = 0ull;
+      if (tid == 0) { s_i[0] = 0x7fffffff; s_i[1] = -1; }
       __syncthreads();
-      const int shf = shifts[lvl]; const unsigned nb = 1u << widths[lvl];
-      for (int i = tid; i < V; i += 1024) {
-        const float p = __expf(logits[i] * inv_t - mx);
+      auto put = [&](float p) {
         const unsigned b = __float_as_uint(p);
-        if ((b & mask) != prefix) continue;
-        const unsigned bin = (b >> shf) & (nb - 1);
-        atomicAdd(&hsum[bin], p);
-        atomicAdd(&hcnt[bin], 1u);
+        if ((b & mask) != prefix) return;
+        const int bin = min((int)((b >> shf) & dmask), nb - 1);               // (top level: 0 <= p <= 1 -> digit <= 127)
+        atomicAdd(&hbin[cpy + bin], ONE | (unsigned long long)(b & lmask));
+      };
+      for (int i = tid; i < nv4; i += 4096) {          // four independent 16-byte loads in flight per lane
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = i + 1024 * u; v[u] = P4[k < nv4 ? k : i]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i + 1024 * u < nv4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) put(v[u][j]);
+          }
       }
+      if (tail0 + tid < V) put(P[tail0 + tid]);
       __syncthreads();
-      if (tid == 0) {                                  // walk bins from the largest value down until the target is crossed
-        float cum = cum_above; int sel = 0;
-        for (int bin = (int)nb - 1; bin >= 0; --bin) {
-          if (hcnt[bin] == 0u) continue;
-          if (cum + hsum[bin] > target) { sel = bin; break; }
-          cum += hsum[bin];
-          sel = bin;                                   // (if never crossed: ends at the lowest occupied bin)
+      // walk from the largest bin down until the target is crossed -- as a workgroup-wide prefix sum: thread t owns the PER
+      // descending positions PER*t .. PER*t + PER-1 (position r <-> bin nb-1-r); copies are merged in registers
+      constexpr int PER = 4;                           // 4096 bins / 1024 threads at the widest level
+      double a[PER]; bool occ[PER]; double mine = 0.0;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int bin = nb - 1 - (PER * tid + j);
+        a[j] = 0.0; occ[j] = false;
+        if (bin >= 0) {
+          unsigned long long h = 0ull;
+          for (int r = 0; r < n_copies; ++r) h += hbin[r * stride + bin];
+          const unsigned bits = prefix | ((unsigned)bin << shf);               // smallest member of the bin
+          const int e = (int)((bits >> 23) & 0xffu);
+          const double ulp = ldexp(1.0, max(e, 1) - 150);
+          const double cnt = (double)(h >> SMP_CNT_SHIFT), low = (double)(h & (ONE - 1ull));
+          a[j] = cnt * (double)__uint_as_float(bits) + low * ulp;
+          occ[j] = (h >> SMP_CNT_SHIFT) != 0ull;
         }
-        s_f[0] = cum; s_i[0] = sel;
+        mine += a[j];
       }
+      double before = cum_above + blk1024_excl_scan<double>(mine, shd);
+      int hit = -1, lowest = -1; double before_hit = 0.0, before_low = 0.0;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (occ[j]) { lowest = PER * tid + j; before_low = before; if (hit < 0 && before + a[j] > target) { hit = PER * tid + j; before_hit = before; } }
+        before += a[j];
+      }
+      if (hit >= 0) atomicMin(&s_i[0], hit);
+      if (lowest >= 0) atomicMax(&s_i[1], lowest);
       __syncthreads();
-      cum_above = s_f[0];
-      prefix |= ((unsigned)s_i[0]) << shf;
-      mask |= (nb - 1) << shf;
+      // never crossed (rounding corner): settle on the lowest occupied bin
+      const bool crossed = s_i[0] != 0x7fffffff;
+      const int sel_r = crossed ? s_i[0] : max(s_i[1], 0);
+      if (crossed ? hit == sel_r : lowest == sel_r) s_d[0] = crossed ? before_hit : before_low;
+      __syncthreads();
+      cum_above = s_d[0];
+      prefix |= ((unsigned)(nb - 1 - sel_r)) << shf;
+      mask |= dmask << shf;
       __syncthreads();
     }
     thr_bits = prefix;
     const float thr = __uint_as_float(thr_bits);
     // ties: keep the smallest k >= 1 with cum_above + k*thr > target
     int k = 1;
-    if (thr > 0.f) { const float need = (target - cum_above) / thr; k = (int)floorf(need) + 1; if (k < 1) k = 1; }
+    if (thr > 0.f) { const double need = (target - cum_above) / (double)thr; k = need >= 2.0e9 ? 0x7fffffff : (int)floor(need) + 1; if (k < 1) k = 1; }
     keep_ties = k;
-    // exact kept sum (threshold ties resolved by index order below)
-    float ks = 0.f; unsigned nt = 0u;
-    for (int i = tid; i < V; i += 1024) {
-      const float p = __expf(logits[i] * inv_t - mx);
-      const unsigned b = __float_as_uint(p);
-      if (b > thr_bits) ks += p; else if (b == thr_bits) ++nt;
-    }
-    ks = blk1024_sum(ks, sh);
-    const float ntf = blk1024_sum((float)nt, sh);
-    if ((float)keep_ties > ntf) keep_ties = (int)ntf;
-    kept_sum = ks + (float)keep_ties * thr;
   }
-  // 4. inverse-CDF draw over the kept tokens in index order with the caller's uniform
-  const float u = uniforms[st->n_gen];
-  const float goal = u * kept_sum;
-  // each wave owns a contiguous index range; lanes stride inside it (coalesced)
-  const int per_wave = (V + 15) / 16;
-  const int w_lo = wave * per_wave, w_hi = min(V, w_lo + per_wave);
-  auto kept_p = [&](int i, int& tie_rank_before) -> float {   // tie handling needs the rank among ties: resolved in the ordered pass
-    const float p = __expf(logits[i] * inv_t - mx);
-    const unsigned b = __float_as_uint(p);
-    if (!use_top_p || b > thr_bits) return p;
-    if (b == thr_bits) { tie_rank_before = 1; return p; }
-    return 0.f;
-  };
-  // ties at the threshold are rare (distinct floats); count ties per wave range to apply "lowest index first"
-  float wsum = 0.f; int wties = 0;
-  for (int i = w_lo + lane; i < w_hi; i += 64) { int t = 0; const float p = kept_p(i, t); if (t) ++wties; else wsum += p; }
-  wsum = wave_sum(wsum);
-  for (int o = 32; o > 0; o >>= 1) wties += __shfl_xor(wties, o, 64);
-  __shared__ float wtot[16];
-  __shared__ int wtie[16];
-  if (lane == 0) { wtot[wave] = wsum; wtie[wave] = wties; }
+  // 4. inverse-CDF draw over the kept tokens in index order with the caller's uniform.
+  //    a) each wave sums the kept probabilities of one contiguous sixteenth of the vocabulary (coalesced float4 loads)
+  const float thr = __uint_as_float(thr_bits);
+  const int per_wave = (((V + 15) / 16) + 3) & ~3;
+  const int w_lo = min(V, wave * per_wave), w_hi = min(V, w_lo + per_wave);
+  {
+    float wsum = 0.f; int wt = 0;
+    auto acc = [&](float p) {
+      const unsigned b = __float_as_uint(p);
+      if (!use_top_p || b > thr_bits) wsum += p; else if (b == thr_bits) ++wt;
+    };
+    const int n4 = (w_hi - w_lo) >> 2;
+    for (int i = lane; i < n4; i += 256) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int k = i + 64 * u; v[u] = *reinterpret_cast<const f32x4*>(P + w_lo + 4 * (k < n4 ? k : i)); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i + 64 * u < n4) { acc(v[u][0]); acc(v[u][1]); acc(v[u][2]); acc(v[u][3]); }
+    }
+    if (w_lo + 4 * n4 + lane < w_hi) acc(P[w_lo + 4 * n4 + lane]);
+    wsum = wave_sum(wsum);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wt += __shfl_xor(wt, o, 64);
+    if (lane == 0) { wtot[wave] = wsum; wtie[wave] = wt; }
+  }
   __syncthreads();
   if (tid == 0) {
-    // serial over 16 ranges: find the range holding the goal (ties counted lowest-index first up to keep_ties)
-    const float thr = __uint_as_float(thr_bits);
-    float cum = 0.f; int ties_used = 0; int sel = 15;
+    // b) serial over the 16 ranges: the kept total, then the range holding the goal (ties count lowest index first, up to keep_ties)
+    int nt = 0; float ks = 0.f;
+    for (int w2 = 0; w2 < 16; ++w2) { nt += wtie[w2]; ks += wtot[w2]; }
+    const int kt = use_top_p ? min(keep_ties, nt) : 0;
+    const float goal = uniforms[st->n_gen] * (ks + (float)kt * thr);
+    float cum = 0.f; int used = 0, sel = -1, last = 0; float cum_last = 0.f; int used_last = 0;
     for (int w2 = 0; w2 < 16; ++w2) {
-      const int tk = use_top_p ? min(wtie[w2], max(0, keep_ties - ties_used)) : 0;
+      const int tk = min(wtie[w2], max(0, kt - used));
       const float add = wtot[w2] + (float)tk * thr;
+      if (add > 0.f) { last = w2; cum_last = cum; used_last = used; }
       if (cum + add > goal) { sel = w2; break; }
-      cum += add; ties_used += tk;
+      cum += add; used += tk;
     }
-    s_f[1] = cum; s_i[1] = sel; s_i[2] = ties_used;
+    if (sel < 0) { sel = last; cum = cum_last; used = used_last; }        // goal >= kept total (rounding): last range that holds anything
+    s_f[1] = cum; s_f[2] = goal; s_i[1] = sel; s_i[2] = used; s_i[3] = kt; s_i[0] = 0x7fffffff; s_i[4] = -1;
   }
   __syncthreads();
-  if (wave == s_i[1]) {                                 // ordered scan of the selected range, 64 elements at a time
-    const float thr = __uint_as_float(thr_bits);
-    float cum = s_f[1]; int ties_used = s_i[2]; int found = -1;
-    for (int base = w_lo; base < w_hi && found < 0; base += 64) {
-      const int i = base + lane;
-      float p = 0.f; int is_tie = 0;
-      if (i < w_hi) { int t = 0; p = kept_p(i, t); is_tie = t; }
-      // rank of tie lanes within this group
-      const unsigned long long tmask = __ballot(is_tie != 0);
-      const int rank = __popcll(tmask & ((1ull << lane) - 1ull));
-      if (is_tie) p = (ties_used + rank < keep_ties) ? thr : 0.f;
-      float incl = p;                                    // inclusive prefix over lanes
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-      const unsigned long long hit = __ballot(p > 0.f && cum + incl > goal);
-      if (hit) found = base + (__ffsll((long long)hit) - 1);
-      cum += __shfl(incl, 63, 64);
-      ties_used += __popcll(tmask);
+  // c) the whole workgroup resolves the selected range: thread t owns CH contiguous tokens, a workgroup-wide prefix sum finds the
+  //    first thread whose chunk crosses the goal, and that thread walks its chunk in index order
+  const int sel = s_i[1], kt = s_i[3], ties0 = s_i[2];
+  const float cum0 = s_f[1], goal = s_f[2];
+  const int r_lo = min(V, sel * per_wave), r_hi = min(V, r_lo + per_wave);
+  const int CH = (per_wave + 1023) / 1024;
+  const int t_lo = min(r_hi, r_lo + tid * CH), t_hi = min(r_hi, t_lo + CH);
+  float tsum = 0.f; int tt = 0; bool any_kept = false;
+  for (int i = t_lo; i < t_hi; ++i) {
+    const float p = P[i]; const unsigned b = __float_as_uint(p);
+    if (!use_top_p || b > thr_bits) { tsum += p; any_kept = any_kept || p > 0.f; } else if (b == thr_bits) ++tt;
+  }
+  const float ex_sum = blk1024_excl_scan<float>(tsum, sh);
+  const int ex_tie = blk1024_excl_scan<int>(tt, shi);
+  const int used_before = min(kt, ties0 + ex_tie), used_after = min(kt, ties0 + ex_tie + tt);
+  const float before = cum0 + ex_sum + (float)(used_before - ties0) * thr;
+  const float after = cum0 + (ex_sum + tsum) + (float)(used_after - ties0) * thr;
+  any_kept = any_kept || (used_after > used_before && thr > 0.f);
+  if (any_kept) { atomicMax(&s_i[4], tid); if (after > goal) atomicMin(&s_i[0], tid); }
+  __syncthreads();
+  const int win = s_i[0] != 0x7fffffff ? s_i[0] : s_i[4];      // no chunk crosses (rounding): the last chunk that holds a kept token
+  if (tid == (win < 0 ? 0 : win)) {
+    int found = -1, last_kept = -1;
+    float cum = before; int used = used_before;
+    for (int i = t_lo; i < t_hi && found < 0; ++i) {
+      const float p = P[i]; const unsigned b = __float_as_uint(p);
+      float kv = 0.f;
+      if (!use_top_p || b > thr_bits) kv = p;
+      else if (b == thr_bits && used < kt) { kv = thr; ++used; }
+      if (kv > 0.f) { last_kept = i; if (cum + kv > goal) found = i; cum += kv; }
     }
-    if (found < 0) {                                     // numerical corner: goal >= kept_sum; fall back to the last kept token of the range
-      for (int i = w_hi - 1; i >= w_lo; --i) { int t = 0; if (kept_p(i, t) > 0.f) { found = i; break; } }
-      if (found < 0) found = w_lo;
+    if (found < 0) found = last_kept >= 0 ? last_kept : min(r_lo, V - 1);
+    const int next = found;
+    const int ng = st->n_gen;
+    if (cur_len < max_ctx) tokens[cur_len] = next;
+    st->n_gen = ng + 1;
+    bool stop = false;
+    for (int k = 0; k < sp.n_stop; ++k) stop = stop || next == sp.stop_ids[k];
+    if (!stop && sp.rep_window > 0) {                  // history is updated only for non-stop tokens (OrpheusTTS.swift:304-326)
+      int nh = st->n_hist;
+      if (nh < sp.rep_window) { hist[nh] = next; st->n_hist = nh + 1; }
+      else { for (int k = 1; k < nh; ++k) hist[k - 1] = hist[k]; hist[nh - 1] = next; }
     }
-    if (lane == 0) {
-      const int next = found;
-      const int ng = st->n_gen;
-      if (cur_len < max_ctx) tokens[cur_len] = next;
-      st->n_gen = ng + 1;
-      bool stop = false;
-      for (int k = 0; k < sp.n_stop; ++k) stop = stop || next == sp.stop_ids[k];
-      if (!stop && sp.rep_window > 0) {                  // history is updated only for non-stop tokens (OrpheusTTS.swift:304-326)
-        int nh = st->n_hist;
-        if (nh < sp.rep_window) { hist[nh] = next; st->n_hist = nh + 1; }
-        else { for (int k = 1; k < nh; ++k) hist[k - 1] = hist[k]; hist[nh - 1] = next; }
-      }
-      if (stop || ng + 1 >= sp.max_new_tokens || cur_len + 1 >= max_ctx) st->finished = 1;
-      st->pos = pos + 1;
-    }
+    if (stop || ng + 1 >= sp.max_new_tokens || cur_len + 1 >= max_ctx) st->finished = 1;
+    st->pos = pos + 1;
   }
 }
+
+// lm_sample needs 128 KB of dynamic LDS: raise the kernel's limit once per process
+int lm_sample_launch(hipStream_t s, float* logits, int V, int32_t* tokens, int32_t* hist, const float* uniforms, LmState* st, const mia_lm_sampler& sp, int n_prompt, int max_ctx) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lm_sample), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMP_LDS_BYTES);
+  if (attr != hipSuccess) return -1;
+  hipLaunchKernelGGL(lm_sample, dim3(1), dim3(1024), SMP_LDS_BYTES, s, logits, V, tokens, hist, uniforms, st, sp, n_prompt, max_ctx);
+  return 0;
+}
+
 
 // ---- RAS sampler of CosyVoice2 (Qwen2LM.swift:295-321, 433-488): nucleus (top-p 0.8 capped at top-k 25, renormalised, drawn in
 // descending-probability order); if the pick already occurs >= win*tau times among the last `win` emitted tokens, redraw from the
 // full softmax; while i < min_len an EOS pick is rejected and the whole trial repeated (<= 100 times).  Every categorical draw is
 // an inverse CDF with the next caller-provided uniform (u_cursor walks the stream).
-struct RasParams { float top_p; int top_k; int win; float tau; int eos; int min_len; int max_len; int n_uniforms; };
 
 __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ logits, int V, int32_t* __restrict__ tokens, int32_t* __restrict__ out_tokens,
                                                       const float* __restrict__ uniforms, LmState* __restrict__ st, RasParams rp, int max_ctx) {
@@ -568,6 +720,17 @@ __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ 
 
 // greedy / plain path: advance only (logits are read back by the host)
 __global__ void lm_advance(LmState* st) { st->pos += 1; }
+__global__ void lm_set_pos(LmState* st, int pos) { st->pos = pos; }
+
+// batched prompt pass: act[r][j] = silu(gu[r][2j]) * gu[r][2j+1] from the fp32 GEMM output (same expression as the SK_SWIGLU epilogue)
+template <typename T>
+__global__ __launch_bounds__(256) void lm_swiglu_rows(const float* __restrict__ gu, uint16_t* __restrict__ act, int64_t n_pairs2) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // two outputs per thread
+  if (e >= n_pairs2) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(gu + 4 * e);
+  const float a = v[0] / (1.0f + __expf(-v[0])) * v[1], b = v[2] / (1.0f + __expf(-v[2])) * v[3];
+  *reinterpret_cast<uint32_t*>(act + 2 * e) = pack2<T>(a, b);
+}
 
 }  // namespace
 
@@ -625,8 +788,8 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
     return skinny_gemm_launch(a, mode, m->dtype, s);
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
-  LAUNCH_T(lm_embed_norm, dim3(1), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps);
-  const size_t att_lds = (size_t)(c.max_ctx + 4 * dh + 8) * 4;
+  LAUNCH_T(lm_embed_norm, dim3(1), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps, -1);
+  const size_t att_lds = (size_t)(c.max_ctx + ATT_NW * dh + 2 * ATT_NW) * 4;
   for (int l = 0; l < c.n_layers; ++l) {
     const LmLayer& L = m->layers[l];
     uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * c.n_kv_heads * c.max_ctx * dh;
@@ -634,14 +797,14 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
     if (skinny(m->h, D, L.wqkv, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL)) return -1;
     const int n_el = (c.n_heads + c.n_kv_heads) * (dh / 2) + Nk;
     LAUNCH_T(lm_rope_cache, dim3((n_el + 255) / 256), dim3(256), 0, m->qkv_part, m->S_qkv, L.bqkv, m->inv_freq, (uint16_t*)m->q, kc, vc, m->state,
-             c.n_heads, c.n_kv_heads, dh, c.max_ctx);
+             c.n_heads, c.n_kv_heads, dh, c.max_ctx, -1);
     const float scale = 1.0f / sqrtf((float)dh);
     if (dh == 128) {
-      if (f16) hipLaunchKernelGGL((lm_attention<F16, 128>), dim3(c.n_heads), dim3(256), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale);
-      else hipLaunchKernelGGL((lm_attention<BF16, 128>), dim3(c.n_heads), dim3(256), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale);
+      if (f16) hipLaunchKernelGGL((lm_attention<F16, 128>), dim3(c.n_heads), dim3(64 * ATT_NW), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, -1);
+      else hipLaunchKernelGGL((lm_attention<BF16, 128>), dim3(c.n_heads), dim3(64 * ATT_NW), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, -1);
     } else {
-      if (f16) hipLaunchKernelGGL((lm_attention<F16, 64>), dim3(c.n_heads), dim3(256), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale);
-      else hipLaunchKernelGGL((lm_attention<BF16, 64>), dim3(c.n_heads), dim3(256), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale);
+      if (f16) hipLaunchKernelGGL((lm_attention<F16, 64>), dim3(c.n_heads), dim3(64 * ATT_NW), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, -1);
+      else hipLaunchKernelGGL((lm_attention<BF16, 64>), dim3(c.n_heads), dim3(64 * ATT_NW), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, -1);
     }
     if (skinny(m->att, Nq, L.wo, nullptr, m->partial, 0, D, Nq, m->S_o, SK_PARTIAL)) return -1;
     LAUNCH_T(lm_reduce_norm, dim3(1), dim3(256), 0, m->partial, m->S_o, L.post_norm, m->x, (uint16_t*)m->h, D, c.rms_eps);
@@ -653,28 +816,110 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
   const int HV = m->head_vocab > 0 ? m->head_vocab : c.vocab;
   if (skinny(m->h, D, m->lm_head, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32)) return -1;
   if (ras) hipLaunchKernelGGL(lm_sample_ras, dim3(1), dim3(1024), 0, s, m->logits, HV, m->tokens, m->out_tokens, m->uniforms, m->state, *ras, c.max_ctx);
-  else if (sampling) hipLaunchKernelGGL(lm_sample, dim3(1), dim3(1024), 0, s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx);
+  else if (sampling) { if (lm_sample_launch(s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx)) return -1; }
   else hipLaunchKernelGGL(lm_advance, dim3(1), dim3(1), 0, s, m->state);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int lm_graph(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_prompt) {
+// ---- batched prompt pass ---------------------------------------------------------------------------
+// Positions [pos0, pos0 + P) of the sequence (token ids already in m->tokens, or embedding rows in m->embeds) go through the
+// layers as rows of bf16/f16 MFMA GEMMs (gemm.hip) instead of P single-row step graphs: one read of the weights per chunk of
+// PF_ROWS positions instead of one per position.  Only the K/V caches are produced -- the caller runs the LAST prompt position
+// through the ordinary step (which owns the head and the sampler), so P = n_prompt - 1.  Per-row arithmetic mirrors the step:
+// fp32 residual stream, 16-bit RMSNorm output, fp32 q|k|v -> RoPE -> 16-bit, same attention kernel (row r sees keys [0, pos0+r]),
+// fp32 gate/up -> silu(g)*u -> 16-bit.  (The reference does the same thing: model(promptIds, cache) is one batched call,
+// OrpheusTTS.swift:262-279 / Qwen2LM.swift:353-361.)
+constexpr int PF_ROWS = 512;
+constexpr int PF_MIN_ROWS = 8;     // below this the step graph is as fast
+
+bool lm_prefill_supported(const mia_lm* m) {
+  static const bool off = getenv("MIA_LM_NO_PREFILL") != nullptr;
+  const mia_lm_config& c = m->cfg;
+  return !off && c.hidden % 64 == 0 && (c.n_heads * c.head_dim) % 64 == 0 && c.inter % 64 == 0;
+}
+
+int lm_prefill(mia_lm* m, int pos0, int P) {
+  mia_ctx* ctx = m->ctx;
+  hipStream_t s = ctx->stream;
+  const mia_lm_config& c = m->cfg;
+  const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh, Nqkv = Nq + 2 * Nk, I = c.inter;
+  const bool f16 = m->dtype == MIA_F16;
+  const size_t b_x = align_up((size_t)PF_ROWS * D * 4, 256), b_h = align_up((size_t)PF_ROWS * D * 2, 256), b_qkv = align_up((size_t)PF_ROWS * Nqkv * 4, 256),
+               b_q = align_up((size_t)PF_ROWS * Nq * 2, 256), b_gu = align_up((size_t)PF_ROWS * 2 * I * 4, 256), b_act = align_up((size_t)PF_ROWS * I * 2, 256);
+  if (!m->pf_buf) {
+    void* p = nullptr;
+    if (hipMalloc(&p, b_x + b_h + b_qkv + 2 * b_q + b_gu + b_act) != hipSuccess) return mia_fail(ctx, MIA_ERR_OUT_OF_MEMORY, "lm: prompt-pass buffers");
+    m->allocs.push_back(p); m->pf_buf = (char*)p;
+  }
+  char* b = m->pf_buf;
+  float* x = (float*)b; b += b_x;
+  uint16_t* h = (uint16_t*)b; b += b_h;
+  float* qkv = (float*)b; b += b_qkv;
+  uint16_t* q = (uint16_t*)b; b += b_q;
+  uint16_t* att = (uint16_t*)b; b += b_q;
+  float* gu = (float*)b; b += b_gu;
+  uint16_t* act = (uint16_t*)b;
+  auto gemm = [&](const void* A, int K, const void* W, const float* bias, float* C, int N, int M, const float* R) {
+    GemmArgs g;
+    g.A = A; g.lda = K; g.W = W; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.out_f32 = 1;
+    if (R) { g.R = R; g.ldr = N; }
+    if (const char* e = mia_gemm_check(g)) { ctx->err = e; return -1; }
+    return mia_gemm_launch(g, m->dtype, s);
+  };
+#define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
+  const size_t att_lds = (size_t)(c.max_ctx + ATT_NW * dh + 2 * ATT_NW) * 4;
+  const float scale = 1.0f / sqrtf((float)dh);
+  for (int r0 = 0; r0 < P; r0 += PF_ROWS) {
+    const int M = std::min(PF_ROWS, P - r0), p0 = pos0 + r0;
+    LAUNCH_T(lm_embed_norm, dim3(M), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, x, h, m->state, D, c.rms_eps, p0);
+    for (int l = 0; l < c.n_layers; ++l) {
+      const LmLayer& L = m->layers[l];
+      uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * c.n_kv_heads * c.max_ctx * dh;
+      uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * c.n_kv_heads * c.max_ctx * dh;
+      if (gemm(h, D, L.wqkv, nullptr, qkv, Nqkv, M, nullptr)) return MIA_ERR_DEVICE;
+      const int n_el = (c.n_heads + c.n_kv_heads) * (dh / 2) + Nk;
+      LAUNCH_T(lm_rope_cache, dim3((n_el + 255) / 256, M), dim3(256), 0, qkv, 1, L.bqkv, m->inv_freq, q, kc, vc, m->state, c.n_heads, c.n_kv_heads, dh, c.max_ctx, p0);
+      if (l + 1 == c.n_layers) break;            // past its K/V rows the last layer feeds only the head, which the prompt pass skips
+      if (dh == 128) {
+        if (f16) hipLaunchKernelGGL((lm_attention<F16, 128>), dim3(c.n_heads, M), dim3(64 * ATT_NW), att_lds, s, q, kc, vc, att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, p0);
+        else hipLaunchKernelGGL((lm_attention<BF16, 128>), dim3(c.n_heads, M), dim3(64 * ATT_NW), att_lds, s, q, kc, vc, att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, p0);
+      } else {
+        if (f16) hipLaunchKernelGGL((lm_attention<F16, 64>), dim3(c.n_heads, M), dim3(64 * ATT_NW), att_lds, s, q, kc, vc, att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, p0);
+        else hipLaunchKernelGGL((lm_attention<BF16, 64>), dim3(c.n_heads, M), dim3(64 * ATT_NW), att_lds, s, q, kc, vc, att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, p0);
+      }
+      if (gemm(att, Nq, L.wo, nullptr, x, D, M, x)) return MIA_ERR_DEVICE;                // x += att . Wo^T
+      LAUNCH_T(lm_reduce_norm, dim3(M), dim3(256), 0, (const float*)nullptr, 0, L.post_norm, x, h, D, c.rms_eps);
+      if (gemm(h, D, L.wgu, nullptr, gu, 2 * I, M, nullptr)) return MIA_ERR_DEVICE;
+      const int64_t n2 = (int64_t)M * I / 2;
+      LAUNCH_T(lm_swiglu_rows, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, gu, act, n2);
+      if (gemm(act, I, L.wdown, nullptr, x, D, M, x)) return MIA_ERR_DEVICE;              // x += act . Wdown^T
+      LAUNCH_T(lm_reduce_norm, dim3(M), dim3(256), 0, (const float*)nullptr, 0, m->layers[l + 1].in_norm, x, h, D, c.rms_eps);
+    }
+  }
+#undef LAUNCH_T
+  hipLaunchKernelGGL(lm_set_pos, dim3(1), dim3(1), 0, s, m->state, pos0 + P);
+  if (hipGetLastError() != hipSuccess) return mia_fail(ctx, MIA_ERR_DEVICE, "lm: prompt-pass launch failed");
+  return MIA_OK;
+}
+
+int lm_graph(mia_lm* m, int mode, const mia_lm_sampler& sp, const RasParams* ras = nullptr) {
   mia_ctx* ctx = m->ctx;
   static const bool no_graph = getenv("MIA_NO_GRAPH") != nullptr;
   if (no_graph) return 1;
-  mia_lm_sampler key = sp; key.max_new_tokens = sampling ? sp.max_new_tokens : 0;
-  // n_prompt is a kernel argument of the sampler: fold it into the key via top_k-unused field
-  if (m->graph_valid && m->graph_sampling == sampling && memcmp(&m->graph_sampler, &key, sizeof(key)) == 0 && m->graph_sampler.reserved == n_prompt) return 0;
+  mia_lm_sampler key{}; RasParams rkey{};
+  if (mode == 1) key = sp;
+  if (mode == 2) rkey = *ras;
+  if (m->graph && m->graph_mode == mode && memcmp(&m->graph_sampler, &key, sizeof(key)) == 0 && memcmp(&m->graph_ras, &rkey, sizeof(rkey)) == 0) return 0;
   if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
   hipGraph_t g = nullptr;
   MIA_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  const int erc = lm_enqueue_step(m, sampling, sp, n_prompt);
+  const int erc = lm_enqueue_step(m, mode != 0, sp, -1, mode == 2 ? ras : nullptr);
   hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
   if (erc != 0 || ce != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return mia_fail(ctx, MIA_ERR_DEVICE, "lm: step graph capture failed"); }
   hipError_t ie = hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
-  if (ie != hipSuccess) return mia_fail(ctx, MIA_ERR_DEVICE, "lm: hipGraphInstantiate failed");
-  m->graph_sampler = key; m->graph_sampler.reserved = n_prompt; m->graph_sampling = sampling; m->graph_valid = true;
+  if (ie != hipSuccess) { m->graph = nullptr; return mia_fail(ctx, MIA_ERR_DEVICE, "lm: hipGraphInstantiate failed"); }
+  m->graph_sampler = key; m->graph_ras = rkey; m->graph_mode = mode;
   return 0;
 }
 
@@ -800,9 +1045,14 @@ extern "C" int mia_lm_forward(mia_lm* m, const int32_t* ids, int n, float* last_
   MIA_HIP(ctx, hipMemcpyAsync(m->tokens + st.pos, ids, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   mia_lm_sampler none{};
-  const int gr = lm_graph(m, false, none, 0);
+  const int gr = lm_graph(m, 0, none);
   if (gr < 0) return gr;
-  for (int i = 0; i < n; ++i) {
+  int done = 0;
+  if (n - 1 >= PF_MIN_ROWS && lm_prefill_supported(m)) {        // all but the last position: K/V only, batched
+    if (const int rc = lm_prefill(m, st.pos, n - 1)) return rc;
+    done = n - 1;
+  }
+  for (int i = done; i < n; ++i) {
     if (gr == 0) MIA_HIP(ctx, hipGraphLaunch(m->graph, ctx->stream));
     else if (lm_enqueue_step(m, false, none, 0)) return mia_fail(ctx, MIA_ERR_DEVICE, "lm_forward: launch failed");
   }
@@ -822,15 +1072,20 @@ extern "C" int mia_lm_generate(mia_lm* m, const int32_t* prompt, int n_prompt, c
   for (int i = 0; i < n_prompt; ++i) MIA_CHECK_ARG(ctx, prompt[i] >= 0 && prompt[i] < m->cfg.vocab, "lm_generate: token %d out of vocabulary", prompt[i]);
   MIA_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  MIA_HIP(ctx, hipMemsetAsync(m->state, 0, sizeof(LmState), s));
+  LmState st{}; st.n_prompt = n_prompt;
+  MIA_HIP(ctx, hipMemcpyAsync(m->state, &st, sizeof(st), hipMemcpyHostToDevice, s));
   MIA_HIP(ctx, hipMemcpyAsync(m->tokens, prompt, (size_t)n_prompt * 4, hipMemcpyHostToDevice, s));
   MIA_HIP(ctx, hipMemcpyAsync(m->uniforms, uniforms, (size_t)sp->max_new_tokens * 4, hipMemcpyHostToDevice, s));
   MIA_HIP(ctx, hipStreamSynchronize(s));
-  const int gr = lm_graph(m, true, *sp, n_prompt);
+  const int gr = lm_graph(m, 1, *sp);
   if (gr < 0) return gr;
   const int total = n_prompt + sp->max_new_tokens - 1;
-  LmState st{};
-  for (int step = 0; step < total; ++step) {
+  int first = 0;
+  if (n_prompt - 1 >= PF_MIN_ROWS && lm_prefill_supported(m)) {   // prompt[0 .. n_prompt-2]: K/V only, batched; the last prompt token takes the first step
+    if (const int rc = lm_prefill(m, 0, n_prompt - 1)) return rc;
+    first = n_prompt - 1;
+  }
+  for (int step = first; step < total; ++step) {
     if (gr == 0) MIA_HIP(ctx, hipGraphLaunch(m->graph, s));
     else if (lm_enqueue_step(m, true, *sp, n_prompt)) return mia_fail(ctx, MIA_ERR_DEVICE, "lm_generate: launch failed");
     if (step >= n_prompt && (step & 15) == 15) {
@@ -869,7 +1124,7 @@ extern "C" int mia_sample_top_p(mia_ctx* ctx, const float* logits, int V, const 
   MIA_HIP(ctx, hipMemcpyAsync(d_u, &uniform, 4, hipMemcpyHostToDevice, s));
   MIA_HIP(ctx, hipMemcpyAsync(d_st, &st, sizeof(st), hipMemcpyHostToDevice, s));
   mia_lm_sampler sp{}; sp.temperature = temperature; sp.top_p = top_p; sp.rep_penalty = rep_penalty; sp.rep_window = 0; sp.max_new_tokens = 1;
-  hipLaunchKernelGGL(lm_sample, dim3(1), dim3(1024), 0, s, d_logits, V, d_tok, d_hist, d_u, d_st, sp, 1, 2);
+  if (lm_sample_launch(s, d_logits, V, d_tok, d_hist, d_u, d_st, sp, 1, 2)) return mia_fail(ctx, MIA_ERR_DEVICE, "sample_top_p: cannot reserve LDS");
   MIA_HIP(ctx, hipGetLastError());
   MIA_HIP(ctx, hipMemcpyAsync(out, d_tok + 1, 4, hipMemcpyDeviceToHost, s));
   MIA_HIP(ctx, hipStreamSynchronize(s));
@@ -897,9 +1152,17 @@ extern "C" int mia_lm_generate_ras(mia_lm* m, const float* prompt_embeds, int n_
   MIA_HIP(ctx, hipStreamSynchronize(s));
   RasParams r{rp->top_p, rp->top_k, rp->win, rp->tau, rp->eos, rp->min_len, rp->max_len, nu};
   mia_lm_sampler none{};
+  const int gr = lm_graph(m, 2, none, &r);
+  if (gr < 0) return gr;
   const int total = n_prompt + rp->max_len - 1;
-  for (int step = 0; step < total; ++step) {
-    if (lm_enqueue_step(m, true, none, n_prompt, &r)) return mia_fail(ctx, MIA_ERR_DEVICE, "lm_generate_ras: launch failed");
+  int first = 0;
+  if (n_prompt - 1 >= PF_MIN_ROWS && lm_prefill_supported(m)) {   // [sos, text, task, prompt speech) rows except the last: K/V only, batched
+    if (const int rc = lm_prefill(m, 0, n_prompt - 1)) return rc;
+    first = n_prompt - 1;
+  }
+  for (int step = first; step < total; ++step) {
+    if (gr == 0) MIA_HIP(ctx, hipGraphLaunch(m->graph, s));
+    else if (lm_enqueue_step(m, true, none, n_prompt, &r)) return mia_fail(ctx, MIA_ERR_DEVICE, "lm_generate_ras: launch failed");
     if (step >= n_prompt && (step & 15) == 15) {
       MIA_HIP(ctx, hipMemcpyAsync(&st, m->state, sizeof(st), hipMemcpyDeviceToHost, s));
       MIA_HIP(ctx, hipStreamSynchronize(s));

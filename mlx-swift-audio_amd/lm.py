@@ -107,6 +107,25 @@ class CausalLM:
         return out[:n.value].tolist()
 
 
+def _generate_ras(self, prompt_embeds, uniforms, min_len, max_len, eos, top_p=0.8, top_k=25, win=10, tau=0.1) -> list[int]:
+    """mia_lm_generate_ras: embedding-row prompt -> RAS-sampled ids (stops at `eos` once min_len ids are out, or at max_len)."""
+    lib = self.ctx.lib
+    if not getattr(lib, "_ras_declared", False):
+        lib.mia_lm_generate_ras.restype = C.c_int
+        lib.mia_lm_generate_ras.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Ras), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        lib._ras_declared = True
+    x = np.ascontiguousarray(prompt_embeds, np.float32)
+    rp = _Ras(top_p, top_k, win, tau, eos, min_len, max_len)
+    u = np.ascontiguousarray(uniforms, np.float32)
+    out = np.zeros(max_len + 1, np.int32)
+    n = C.c_int32(0)
+    self.ctx.check(lib.mia_lm_generate_ras(self.h, x.ctypes.data, x.shape[0], C.byref(rp), u.ctypes.data, u.size, out.ctypes.data, C.byref(n)))
+    return out[:n.value].tolist()
+
+
+CausalLM.generate_ras = _generate_ras
+
+
 def sample_next_token(ctx: _lib.Context, logits: np.ndarray, history, uniform: float, temperature=0.6, top_p=0.8, rep_penalty=1.3) -> int:
     """sampleNextToken(logits:history:temperature:topP:repetitionPenalty:) with an explicit uniform for the categorical draw."""
     _declare(ctx.lib)
@@ -161,18 +180,7 @@ class Qwen2LM:
                   top_p=0.8, top_k=25, win=10, tau=0.1) -> list[int]:
         x = self.lm_input(text, prompt_text, prompt_speech_tokens)
         min_len, max_len = int(len(text) * min_token_text_ratio), int(len(text) * max_token_text_ratio)
-        _declare(self.lm.ctx.lib)
-        lib = self.lm.ctx.lib
-        if not getattr(lib, "_ras_declared", False):
-            lib.mia_lm_generate_ras.restype = C.c_int
-            lib.mia_lm_generate_ras.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Ras), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-            lib._ras_declared = True
-        rp = _Ras(top_p, top_k, win, tau, self.speech_token_size, min_len, max_len)
-        u = np.ascontiguousarray(uniforms, np.float32)
-        out = np.zeros(max_len + 1, np.int32)
-        n = C.c_int32(0)
-        self.lm.ctx.check(lib.mia_lm_generate_ras(self.lm.h, x.ctypes.data, x.shape[0], C.byref(rp), u.ctypes.data, u.size, out.ctypes.data, C.byref(n)))
-        return out[:n.value].tolist()
+        return self.lm.generate_ras(x, uniforms, min_len, max_len, self.speech_token_size, top_p, top_k, win, tau)
 
 
 class OrpheusTTS:

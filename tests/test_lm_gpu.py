@@ -41,6 +41,34 @@ def test_forward_logits_match_oracle(ctx, cfg_name, dtype_name):
     model.close()
 
 
+@pytest.mark.parametrize("cfg_name,n,max_ctx", [("llama-micro", 40, 256), ("llama-micro128", 131, 256), ("qwen-micro", 700, 1024)])
+def test_batched_prompt_pass_matches_stepping(ctx, cfg_name, n, max_ctx):
+    """forward(ids) ingests ids[:-1] through the batched prompt pass (MFMA GEMM rows, chunks of 512 positions); feeding the same
+    ids one call at a time takes the single-row step graph for every position.  Same K/V rows up to fp32 summation order, so the
+    last-position logits agree far inside the oracle tolerance, and both agree with the oracle."""
+    import dataclasses
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    cfg = dataclasses.replace(S.LM_CONFIGS[cfg_name], max_ctx=max_ctx)
+    w = S.lm_weights(cfg, seed=6, round_to="bf16")
+    model = HL.CausalLM.load(ctx, cfg, w, m.BF16)
+    ids = np.random.default_rng(n).integers(0, cfg.vocab, n).tolist()
+    batched = model.forward(ids)
+    nxt_b = model.forward([9])                      # a decode step on the K/V rows the prompt pass wrote
+    model.reset()
+    for t in ids[:-1]:
+        model.forward([t])
+    stepped = model.forward([ids[-1]])
+    nxt_s = model.forward([9])
+    scale = stepped.std()
+    assert np.abs(batched - stepped).max() <= 0.02 * scale, np.abs(batched - stepped).max() / scale
+    assert np.abs(nxt_b - nxt_s).max() <= 0.02 * scale
+    if n <= 200:
+        ref = OL.LMOracle(cfg, w).forward(ids).numpy()[-1]
+        assert np.abs(batched - ref).max() <= 0.08 * ref.std()
+    model.close()
+
+
 def test_sampler_matches_oracle(ctx):
     from mlx_swift_audio_amd import lm as HL
     rng = np.random.default_rng(0)
