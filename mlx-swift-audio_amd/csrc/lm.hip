@@ -200,31 +200,75 @@ __global__ __launch_bounds__(256) void lm_rope_cache(const float* __restrict__ p
 // 16 waves per workgroup: a decode step has only n_heads workgroups, so the key loop's memory latency is hidden by waves of
 // the same workgroup (4 waves: +12 us per layer per 300 keys on Orpheus-3B; 16 waves: a quarter of that).
 constexpr int ATT_NW = 16;
-template <typename T, int DH>
-__global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
-                                                    uint16_t* __restrict__ out, const LmState* __restrict__ st, int Hq, int Hkv, int max_ctx, float scale, int pos0) {
-  extern __shared__ float sc[];            // [max_ctx] scores, then red[ATT_NW][DH] + red2[2 * ATT_NW]
+// FUSED (the decode step): the workgroup first finishes its own q head and its K/V head's new row from the split-K slices of the
+// q|k|v GEMM (sum + bias + RoPE, exactly lm_rope_cache's arithmetic and 16-bit rounding), keeps them in LDS, and the first query
+// head of each group writes the K/V row to the cache -- one kernel less per layer; the new row is used from LDS because the
+// writer may be another workgroup.
+template <typename T, int DH, bool FUSED>
+__global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __restrict__ q, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
+                                                    uint16_t* __restrict__ out, const LmState* __restrict__ st, int Hq, int Hkv, int max_ctx, float scale, int pos0,
+                                                    const float* __restrict__ part, int S, const float* __restrict__ bias, const float* __restrict__ inv_freq) {
+  extern __shared__ float sc[];            // [max_ctx] scores, then red[ATT_NW][DH] + red2[2 * ATT_NW] (+ FUSED: q, k, v rows [3][DH])
   constexpr int LPK = DH / 8;              // lanes per key
   constexpr int KPW = 64 / LPK;            // keys per wave instruction
   float* red = sc + max_ctx;
   float* red2 = red + ATT_NW * DH;
+  float* qs = red2 + 2 * ATT_NW;           // FUSED only
+  float* kn = qs + DH;
+  float* vn = kn + DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, kvh = h / (Hq / Hkv);
   const int nk = (pos0 < 0 ? st->pos : pos0) + (int)blockIdx.y + 1;
+  const int nkc = FUSED ? nk - 1 : nk;     // keys read from the cache
   q += (int64_t)blockIdx.y * Hq * DH; out += (int64_t)blockIdx.y * Hq * DH;
   const int c = lane % LPK, g = lane / LPK;
   const uint16_t* kb = kc + (int64_t)kvh * max_ctx * DH;
   const uint16_t* vb = vc + (int64_t)kvh * max_ctx * DH;
+  if (FUSED) {
+    constexpr int half = DH / 2;
+    const int Nq = Hq * DH, Nk = Hkv * DH, N = Nq + 2 * Nk, pos = nk - 1;
+    const bool writer = h % (Hq / Hkv) == 0;
+    auto val = [&](int n) {                // S <= 4 slices, loads issued together
+      float pv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pv[k] = part[(int64_t)(k < S ? k : S - 1) * N + n];
+      float a = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k < S) a += pv[k];
+      return a;
+    };
+    if (tid < DH) {                        // rotation pairs (i, i + half): the q head, then the k head
+      const bool is_k = tid >= half;
+      const int i = is_k ? tid - half : tid;
+      const int base = is_k ? Nq + kvh * DH : h * DH;
+      const float x0 = val(base + i), x1 = val(base + i + half);
+      float sn, cs;
+      sincosf((float)pos * inv_freq[i], &sn, &cs);
+      const uint16_t r0 = T::from_f32(x0 * cs - x1 * sn), r1 = T::from_f32(x1 * cs + x0 * sn);
+      float* dst = is_k ? kn : qs;
+      dst[i] = T::to_f32(r0); dst[i + half] = T::to_f32(r1);
+      if (is_k && writer) { uint16_t* k = kc + ((int64_t)kvh * max_ctx + pos) * DH; k[i] = r0; k[i + half] = r1; }
+    } else if (tid < 2 * DH) {
+      const int d = tid - DH;
+      const uint16_t r = T::from_f32(val(Nq + Nk + kvh * DH + d));
+      vn[d] = T::to_f32(r);
+      if (writer) vc[((int64_t)kvh * max_ctx + pos) * DH + d] = r;
+    }
+    __syncthreads();
+  }
   float qf[8];
-  {
+  if (FUSED) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[j] = qs[c * 8 + j];
+  } else {
     const s16x8 qv = *reinterpret_cast<const s16x8*>(q + h * DH + c * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = T::to_f32((uint16_t)qv[j]);
   }
-  for (int k0 = wave * KPW * 4; k0 < nk; k0 += ATT_NW * KPW * 4) {
+  for (int k0 = wave * KPW * 4; k0 < nkc; k0 += ATT_NW * KPW * 4) {
     s16x8 kv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { int key = k0 + KPW * u + g; key = key < nk ? key : nk - 1; kv[u] = *reinterpret_cast<const s16x8*>(kb + (int64_t)key * DH + c * 8); }
+    for (int u = 0; u < 4; ++u) { int key = k0 + KPW * u + g; key = key < nkc ? key : nkc - 1; kv[u] = *reinterpret_cast<const s16x8*>(kb + (int64_t)key * DH + c * 8); }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float dot = 0.f;
@@ -233,8 +277,16 @@ __global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __re
 #pragma unroll
       for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);
       const int key = k0 + KPW * u + g;
-      if (c == 0 && key < nk) sc[key] = dot * scale;
+      if (c == 0 && key < nkc) sc[key] = dot * scale;
     }
+  }
+  if (FUSED && wave == 0) {                // the new key, from LDS (same lane split and summation order as a cached key)
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dot += qf[j] * kn[c * 8 + j];
+#pragma unroll
+    for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);
+    if (lane == 0) sc[nk - 1] = dot * scale;
   }
   __syncthreads();
   float m = -INFINITY;
@@ -256,18 +308,23 @@ __global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __re
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int k0 = wave * KPW * 4; k0 < nk; k0 += ATT_NW * KPW * 4) {
+  for (int k0 = wave * KPW * 4; k0 < nkc; k0 += ATT_NW * KPW * 4) {
     s16x8 vv[4]; float pw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int key = k0 + KPW * u + g; const int k2 = key < nk ? key : nk - 1;
+      const int key = k0 + KPW * u + g; const int k2 = key < nkc ? key : nkc - 1;
       vv[u] = *reinterpret_cast<const s16x8*>(vb + (int64_t)k2 * DH + c * 8);
-      pw[u] = key < nk ? sc[k2] : 0.f;
+      pw[u] = key < nkc ? sc[k2] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += pw[u] * T::to_f32((uint16_t)vv[u][j]);
+  }
+  if (FUSED && wave == 0 && g == 0) {      // the new row's contribution
+    const float pw = sc[nk - 1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += pw * vn[c * 8 + j];
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -778,6 +835,22 @@ struct LmLoader {
 
 int pick_split(int K, int want) { for (int s = want; s > 1; --s) if (K % (32 * s) == 0) return s; return 1; }
 
+// one launch site for the eight (dtype, head_dim, fused) instances
+int lm_launch_attention(mia_lm* m, bool fused, int rows, const void* q, uint16_t* kc, uint16_t* vc, void* att, int pos0, const float* part, int S, const float* bias) {
+  const mia_lm_config& c = m->cfg;
+  hipStream_t s = m->ctx->stream;
+  const int dh = c.head_dim;
+  const size_t lds = (size_t)(c.max_ctx + ATT_NW * dh + 2 * ATT_NW + 3 * dh) * 4;
+  const float scale = 1.0f / sqrtf((float)dh);
+  const dim3 grid(c.n_heads, rows), block(64 * ATT_NW);
+#define ATT_GO(TT, DD, FF) hipLaunchKernelGGL((lm_attention<TT, DD, FF>), grid, block, lds, s, (const uint16_t*)q, kc, vc, (uint16_t*)att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, pos0, part, S, bias, m->inv_freq)
+  const bool f16 = m->dtype == MIA_F16;
+  if (dh == 128) { if (fused) { if (f16) ATT_GO(F16, 128, true); else ATT_GO(BF16, 128, true); } else { if (f16) ATT_GO(F16, 128, false); else ATT_GO(BF16, 128, false); } }
+  else           { if (fused) { if (f16) ATT_GO(F16, 64, true); else ATT_GO(BF16, 64, true); } else { if (f16) ATT_GO(F16, 64, false); else ATT_GO(BF16, 64, false); } }
+#undef ATT_GO
+  return 0;
+}
+
 int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_prompt, const RasParams* ras = nullptr) {
   hipStream_t s = m->ctx->stream;
   const mia_lm_config& c = m->cfg;
@@ -789,23 +862,12 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
   LAUNCH_T(lm_embed_norm, dim3(1), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps, -1);
-  const size_t att_lds = (size_t)(c.max_ctx + ATT_NW * dh + 2 * ATT_NW) * 4;
   for (int l = 0; l < c.n_layers; ++l) {
     const LmLayer& L = m->layers[l];
     uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * c.n_kv_heads * c.max_ctx * dh;
     uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * c.n_kv_heads * c.max_ctx * dh;
     if (skinny(m->h, D, L.wqkv, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL)) return -1;
-    const int n_el = (c.n_heads + c.n_kv_heads) * (dh / 2) + Nk;
-    LAUNCH_T(lm_rope_cache, dim3((n_el + 255) / 256), dim3(256), 0, m->qkv_part, m->S_qkv, L.bqkv, m->inv_freq, (uint16_t*)m->q, kc, vc, m->state,
-             c.n_heads, c.n_kv_heads, dh, c.max_ctx, -1);
-    const float scale = 1.0f / sqrtf((float)dh);
-    if (dh == 128) {
-      if (f16) hipLaunchKernelGGL((lm_attention<F16, 128>), dim3(c.n_heads), dim3(64 * ATT_NW), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, -1);
-      else hipLaunchKernelGGL((lm_attention<BF16, 128>), dim3(c.n_heads), dim3(64 * ATT_NW), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, -1);
-    } else {
-      if (f16) hipLaunchKernelGGL((lm_attention<F16, 64>), dim3(c.n_heads), dim3(64 * ATT_NW), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, -1);
-      else hipLaunchKernelGGL((lm_attention<BF16, 64>), dim3(c.n_heads), dim3(64 * ATT_NW), att_lds, s, (const uint16_t*)m->q, kc, vc, (uint16_t*)m->att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, -1);
-    }
+    lm_launch_attention(m, true, 1, nullptr, kc, vc, m->att, -1, m->qkv_part, m->S_qkv, L.bqkv);      // RoPE + cache row + attention
     if (skinny(m->att, Nq, L.wo, nullptr, m->partial, 0, D, Nq, m->S_o, SK_PARTIAL)) return -1;
     LAUNCH_T(lm_reduce_norm, dim3(1), dim3(256), 0, m->partial, m->S_o, L.post_norm, m->x, (uint16_t*)m->h, D, c.rms_eps);
     if (skinny(m->h, D, L.wgu, nullptr, m->act, c.inter, 2 * c.inter, D, 1, SK_SWIGLU)) return -1;
@@ -867,8 +929,6 @@ int lm_prefill(mia_lm* m, int pos0, int P) {
     return mia_gemm_launch(g, m->dtype, s);
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
-  const size_t att_lds = (size_t)(c.max_ctx + ATT_NW * dh + 2 * ATT_NW) * 4;
-  const float scale = 1.0f / sqrtf((float)dh);
   for (int r0 = 0; r0 < P; r0 += PF_ROWS) {
     const int M = std::min(PF_ROWS, P - r0), p0 = pos0 + r0;
     LAUNCH_T(lm_embed_norm, dim3(M), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, x, h, m->state, D, c.rms_eps, p0);
@@ -880,13 +940,7 @@ int lm_prefill(mia_lm* m, int pos0, int P) {
       const int n_el = (c.n_heads + c.n_kv_heads) * (dh / 2) + Nk;
       LAUNCH_T(lm_rope_cache, dim3((n_el + 255) / 256, M), dim3(256), 0, qkv, 1, L.bqkv, m->inv_freq, q, kc, vc, m->state, c.n_heads, c.n_kv_heads, dh, c.max_ctx, p0);
       if (l + 1 == c.n_layers) break;            // past its K/V rows the last layer feeds only the head, which the prompt pass skips
-      if (dh == 128) {
-        if (f16) hipLaunchKernelGGL((lm_attention<F16, 128>), dim3(c.n_heads, M), dim3(64 * ATT_NW), att_lds, s, q, kc, vc, att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, p0);
-        else hipLaunchKernelGGL((lm_attention<BF16, 128>), dim3(c.n_heads, M), dim3(64 * ATT_NW), att_lds, s, q, kc, vc, att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, p0);
-      } else {
-        if (f16) hipLaunchKernelGGL((lm_attention<F16, 64>), dim3(c.n_heads, M), dim3(64 * ATT_NW), att_lds, s, q, kc, vc, att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, p0);
-        else hipLaunchKernelGGL((lm_attention<BF16, 64>), dim3(c.n_heads, M), dim3(64 * ATT_NW), att_lds, s, q, kc, vc, att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, p0);
-      }
+      lm_launch_attention(m, false, M, q, kc, vc, att, p0, nullptr, 0, nullptr);
       if (gemm(att, Nq, L.wo, nullptr, x, D, M, x)) return MIA_ERR_DEVICE;                // x += att . Wo^T
       LAUNCH_T(lm_reduce_norm, dim3(M), dim3(256), 0, (const float*)nullptr, 0, L.post_norm, x, h, D, c.rms_eps);
       if (gemm(h, D, L.wgu, nullptr, gu, 2 * I, M, nullptr)) return MIA_ERR_DEVICE;
