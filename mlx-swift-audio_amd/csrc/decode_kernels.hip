@@ -607,8 +607,8 @@ __global__ __launch_bounds__(1024) void dec_head(HeadBufs hb, DecodeParams p) {
 // (max, argmax, exp-sum) pairs taken relative to the slice's own maxima; phase 2 rescales and merges the records in slice order and
 // applies exactly the decision logic of dec_head.  Sampling (temperature > 0) keeps the single-workgroup kernel.
 // ------------------------------------------------------------------------------------------------
-constexpr int HEAD_SPLIT = 8;
-constexpr int HEAD_NPT2 = 26;      // logits per thread: 256 threads * 26 * 8 slices >= V
+constexpr int HEAD_SPLIT = 32;   // <= 64: dec_head_final merges one record per lane
+constexpr int HEAD_NPT2 = 7;       // logits per thread: 256 threads * 7 * 32 slices >= V
 struct HeadRule {
   bool active, decide, heuristic, sup_ts_all, sup_text_below_eot, sup_below_tsb;
   int ts_floor, max_first, num_gen, cur_len;
@@ -726,33 +726,34 @@ __global__ __launch_bounds__(256) void dec_head_final(HeadBufs hb, DecodeParams 
   __shared__ int s_newpos;
   __shared__ float sh[4];
   const int b = blockIdx.x, tid = threadIdx.x;
+  // wave 0 merges the clip's slice records, one per lane: maxima by butterfly, then the exp-sums rescaled to the merged maxima
+  // (fixed butterfly order: deterministic)
+  float mx_text = -INFINITY, mx_ts = -INFINITY, s_all = 0.f, s_ts = 0.f, fA = 0.f, fB = 0.f;
+  ArgMax bA{-INFINITY, 0x7fffffff}, bB{-INFINITY, 0x7fffffff};
+  const HeadRule r = head_rule(hb, p, b);
+  if (tid < 64 && r.active) {
+    HeadPart me{-INFINITY, -INFINITY, 0.f, 0.f, -INFINITY, -INFINITY, 0.f, 0.f, 0x7fffffff, 0x7fffffff};
+    if (tid < HEAD_SPLIT) me = parts[b * HEAD_SPLIT + tid];
+    mx_text = wave_max(me.mx_text); mx_ts = wave_max(me.mx_ts);
+    bA = wave_amax(ArgMax{me.bAv, me.bAi}); bB = wave_amax(ArgMax{me.bBv, me.bBi});
+    const float mx_all = fmaxf(mx_text, mx_ts);
+    const float ml = fmaxf(me.mx_text, me.mx_ts);
+    s_all = wave_sum(ml > -INFINITY ? me.s_all * __expf(ml - mx_all) : 0.f);
+    s_ts = wave_sum(me.mx_ts > -INFINITY ? me.s_ts * __expf(me.mx_ts - mx_ts) : 0.f);
+    fA = wave_sum(me.bAv > -INFINITY ? me.fA * __expf(me.bAv - bA.v) : 0.f);
+    fB = wave_sum(me.bBv > -INFINITY ? me.fB * __expf(me.bBv - bB.v) : 0.f);
+  }
   if (tid == 0) {
     int newpos = -1;
     const int pos = hb.clip.pos[b];
     const int n_initial = hb.clip.n_init[b], sot_index = hb.clip.sot_idx[b];
-    const HeadRule r = head_rule(hb, p, b);
     if (!r.active) {
       if (r.cur_len < n_initial) newpos = pos + 1;    // forced token, no probe: just advance (a finished clip idles)
     } else {
       const int V = p.V, tsb = p.timestamp_begin;
       const float* lg = hb.logits + (int64_t)b * V;
       int32_t* toks = hb.tokens + (int64_t)b * p.n_ctx;
-      const HeadPart* pt = parts + b * HEAD_SPLIT;
-      float mx_text = -INFINITY, mx_ts = -INFINITY;
-      ArgMax bA{-INFINITY, 0x7fffffff}, bB{-INFINITY, 0x7fffffff};
-      for (int k = 0; k < HEAD_SPLIT; ++k) {
-        mx_text = fmaxf(mx_text, pt[k].mx_text); mx_ts = fmaxf(mx_ts, pt[k].mx_ts);
-        bA = amax(bA, ArgMax{pt[k].bAv, pt[k].bAi}); bB = amax(bB, ArgMax{pt[k].bBv, pt[k].bBi});
-      }
       const float mx_all = fmaxf(mx_text, mx_ts);
-      float s_all = 0.f, s_ts = 0.f, fA = 0.f, fB = 0.f;
-      for (int k = 0; k < HEAD_SPLIT; ++k) {
-        const float ml = fmaxf(pt[k].mx_text, pt[k].mx_ts);
-        if (ml > -INFINITY) s_all += pt[k].s_all * __expf(ml - mx_all);
-        if (pt[k].mx_ts > -INFINITY) s_ts += pt[k].s_ts * __expf(pt[k].mx_ts - mx_ts);
-        if (pt[k].bAv > -INFINITY) fA += pt[k].fA * __expf(pt[k].bAv - bA.v);
-        if (pt[k].bBv > -INFINITY) fB += pt[k].fB * __expf(pt[k].bBv - bB.v);
-      }
       const float lse = mx_all + __logf(s_all);
       if (pos == sot_index) hb.no_speech[b] = __expf(lg[p.no_speech] - lse);
       if (!r.decide) newpos = pos + 1;
