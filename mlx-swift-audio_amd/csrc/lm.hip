@@ -653,10 +653,12 @@ int lm_sample_launch(hipStream_t s, float* logits, int V, int32_t* tokens, int32
 // full softmax; while i < min_len an EOS pick is rejected and the whole trial repeated (<= 100 times).  Every categorical draw is
 // an inverse CDF with the next caller-provided uniform (u_cursor walks the stream).
 
+constexpr int RAS_NPT = 8;      // logits a thread keeps in registers: V <= 8192 (CosyVoice2: 6561 speech tokens + 3)
 __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ logits, int V, int32_t* __restrict__ tokens, int32_t* __restrict__ out_tokens,
                                                       const float* __restrict__ uniforms, LmState* __restrict__ st, RasParams rp, int max_ctx) {
   __shared__ float sh[16];
-  __shared__ int shi[16];
+  __shared__ float shv[2][16];
+  __shared__ int shi[2][16];
   __shared__ float topv[32];
   __shared__ int topi[32];
   __shared__ int s_tok[2];
@@ -665,38 +667,44 @@ __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ 
   const int cur_len = pos + 1;
   if (cur_len < n_prompt || st->finished) { __syncthreads(); if (tid == 0 && !st->finished) st->pos = pos + 1; return; }
   const int step_i = cur_len - n_prompt;                 // loop index i of inferenceLoop
-  // softmax statistics
+  // the whole row lives in registers (thread t holds ids t, t + 1024, ...): one read of the logits for the statistics and
+  // all top-k rounds (re-reading them per round with a `taken` list cost 300 us per token at V = 6564)
+  float x[RAS_NPT];
+#pragma unroll
+  for (int u = 0; u < RAS_NPT; ++u) { const int i = tid + 1024 * u; x[u] = i < V ? logits[i] : -INFINITY; }
   float mx = -INFINITY;
-  for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, logits[i]);
+#pragma unroll
+  for (int u = 0; u < RAS_NPT; ++u) mx = fmaxf(mx, x[u]);
   mx = blk1024_max(mx, sh);
   float tot = 0.f;
-  for (int i = tid; i < V; i += 1024) tot += __expf(logits[i] - mx);
+#pragma unroll
+  for (int u = 0; u < RAS_NPT; ++u) if (tid + 1024 * u < V) tot += __expf(x[u] - mx);
   tot = blk1024_sum(tot, sh);
-  // top-k by iterated block argmax (k <= 32): (value, index) with lowest index on ties; previously taken entries are skipped
+  // top-k by iterated workgroup argmax (k <= 32): (value, index) with lowest index on ties; a taken entry is struck out in its
+  // owner's register.  One barrier per round: the wave winners go to a double-buffered LDS row and every thread merges them.
   const int K = rp.top_k < 32 ? rp.top_k : 32;
   for (int r = 0; r < K; ++r) {
     float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 1024) {
-      const float v = logits[i];
-      bool taken = false;
-      for (int q = 0; q < r; ++q) taken = taken || topi[q] == i;
-      if (!taken && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
-    }
+#pragma unroll
+    for (int u = 0; u < RAS_NPT; ++u) { const int i = tid + 1024 * u; if (i < V && x[u] > bv) { bv = x[u]; bi = i; } }   // ascending i: first maximum wins
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
+    const int buf = r & 1;
+    if (lane == 0) { shv[buf][wave] = bv; shi[buf][wave] = bi; }
     __syncthreads();
-    if (lane == 0) { sh[wave] = bv; shi[wave] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-      float v = sh[0]; int ix = shi[0];
-      for (int w2 = 1; w2 < 16; ++w2) if (sh[w2] > v || (sh[w2] == v && shi[w2] < ix)) { v = sh[w2]; ix = shi[w2]; }
-      topv[r] = __expf(v - mx) / tot; topi[r] = ix;
+    float v = shv[buf][0]; int ix = shi[buf][0];
+#pragma unroll
+    for (int w2 = 1; w2 < 16; ++w2) { const float ov = shv[buf][w2]; const int oi = shi[buf][w2]; if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; } }
+    if (tid == 0) { topv[r] = __expf(v - mx) / tot; topi[r] = ix; }
+    if (ix != 0x7fffffff && (ix & 1023) == tid) {
+#pragma unroll
+      for (int u = 0; u < RAS_NPT; ++u) if ((ix >> 10) == u) x[u] = -INFINITY;
     }
-    __syncthreads();
   }
+  __syncthreads();
   // per-wave partial sums of the full softmax in index order (for the fallback draw)
   const int per_wave = (V + 15) / 16;
   const int w_lo = wave * per_wave, w_hi = min(V, w_lo + per_wave);
@@ -1195,6 +1203,7 @@ extern "C" int mia_lm_generate_ras(mia_lm* m, const float* prompt_embeds, int n_
   MIA_CHECK_ARG(ctx, prompt_embeds && n_prompt > 0 && rp && uniforms && n_uniforms > 0 && out_tokens && n_out, "lm_generate_ras: null arguments");
   MIA_CHECK_ARG(ctx, m->gen_embed && m->head_vocab > 0, "lm_generate_ras: model has no speech_embedding / llm_decoder tensors");
   MIA_CHECK_ARG(ctx, rp->max_len > 0 && n_prompt + rp->max_len <= m->cfg.max_ctx, "lm_generate_ras: prompt + max_len exceeds max_ctx");
+  MIA_CHECK_ARG(ctx, m->head_vocab <= 1024 * RAS_NPT && rp->top_k <= m->head_vocab, "lm_generate_ras: llm_decoder has %d rows; the RAS sampler holds at most %d", m->head_vocab, 1024 * RAS_NPT);
   MIA_CHECK_ARG(ctx, rp->top_k > 0 && rp->top_k <= 32 && rp->win >= 0 && rp->win <= 64 && rp->eos >= 0 && rp->eos < m->head_vocab, "lm_generate_ras: bad sampler parameters");
   MIA_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
