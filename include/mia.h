@@ -391,6 +391,32 @@ int mia_flow_encode(mia_flow* f, const int32_t* token, int n_token, float* mu, i
 int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
                        int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, float* mel, int mem);
 
+/* ---- CAM++ speaker encoder (CosyVoice2 prepareConditionals, once per speaker) ---------------------------------
+ * Replaces CAMPlusSpeakerEncoder (TTS/CosyVoice2/SpeakerEncoder/CAMPlusSpeakerEncoder.swift:12-150, called at
+ * TTS/CosyVoice2/CosyVoice2TTS.swift:409) = Codec/S3Gen/CAMPPlus.swift: kaldiFbankCAMPPlus :32-108, CAMPPlus :687-785,
+ * CAMPPlus.inference :788-818, in the one configuration that wrapper builds (80 fbank bins, 192-d embedding, growth 32,
+ * bottleneck 4 x 32, 128 initial channels, "batchnorm-relu", segment output).  BatchNorm uses its running statistics. */
+#define MIA_CAMPPLUS_DIM 192
+typedef struct mia_campplus mia_campplus;
+/* float32 tensors with the reference's Module key paths ("campplus." prefix already stripped, CAMPlusSpeakerEncoder.swift:93-104):
+ * head.{conv1,conv2}.weight [32][3][3][Cin], head.{bn1,bn2}.{weight,bias,running_mean,running_var},
+ * head.layer{1,2}.{0,1}.{conv1,conv2}.weight, .{bn1,bn2}.*, head.layer{1,2}.0.shortcut.{0.weight [32][1][1][32], 1.*},
+ * tdnn.linear.weight [128][5][320], tdnn.nonlinear.0.*, blocks.B.layers.I.{nonlinear1.0.*, linear1.weight [128][1][Cin],
+ * nonlinear2.0.*, cam_layer.linear_local.weight [32][3][128], cam_layer.linear1.{weight [64][1][128], bias},
+ * cam_layer.linear2.{weight [32][1][64], bias}}, transits.B.{nonlinear.0.*, linear.weight}, out_nonlinear.0.*,
+ * dense.linear.weight [192][1][1024], dense.nonlinear.0.{running_mean,running_var}. */
+mia_campplus* mia_campplus_load(mia_ctx* ctx, const mia_tensor_view* tensors, int n_tensors);
+void mia_campplus_free(mia_campplus* m);
+/* kaldiFbankCAMPPlus (CAMPPlus.swift:32-108): pcm float32 mono 16 kHz [n_samples >= 400] -> fbank float32
+ * [mia_kaldi_fbank_frames(n_samples)][80] (frame-major).  mean_norm != 0 also removes each bin's mean over time (:797-799),
+ * which is what the encoder consumes; 0 gives extractFbank's raw features (CAMPlusSpeakerEncoder.swift:138-150). */
+int64_t mia_kaldi_fbank_frames(int64_t n_samples);
+int mia_campplus_fbank(mia_campplus* m, const float* pcm, int64_t n_samples, int mean_norm, float* fbank, int mem);
+/* CAMPPlus.callAsFunction (:755-785) for one clip: feats float32 [n_frames][80] -> emb float32 [192]. */
+int mia_campplus_forward(mia_campplus* m, const float* feats, int n_frames, float* emb, int mem);
+/* CAMPPlus.inference (:788-818) for one clip: pcm float32 mono 16 kHz [n_samples] -> emb float32 [192]. */
+int mia_campplus_embed(mia_campplus* m, const float* pcm, int64_t n_samples, float* emb, int mem);
+
 #ifdef __cplusplus
 }
 #endif

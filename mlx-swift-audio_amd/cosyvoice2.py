@@ -1,7 +1,7 @@
 """Host-side mirror of CosyVoice2Model (TTS/CosyVoice2/CosyVoice2Model.swift:28-208) and of the tensor part of
 prepareConditionals (TTS/CosyVoice2/CosyVoice2TTS.swift:370-430): generateTokens -> tokensToMel -> melToAudio, every stage on
-the gfx950 HIP layer.  Text tokenisation and the CAM++ speaker encoder stay with the caller
-(CPU text code / one-off per speaker), so text arrives as token ids and the speaker as its 192-d embedding.
+the gfx950 HIP layer, including the CAM++ speaker embedding of the reference clip (speaker.py).  Text tokenisation stays with the
+caller (CPU text code), so text arrives as token ids.
 Every random draw of the reference is an explicit argument: `uniforms` (RAS sampler), `z` (CFM noise), `noise` (HiFT source)."""
 from __future__ import annotations
 
@@ -20,12 +20,13 @@ class CosyVoice2Conditionals:
 
 
 class CosyVoice2Model:
-    def __init__(self, ctx, llm, flow, hifigan, s3_tokenizer=None):
-        self.ctx, self.llm, self.flow, self.hifigan, self.s3 = ctx, llm, flow, hifigan, s3_tokenizer
+    def __init__(self, ctx, llm, flow, hifigan, s3_tokenizer=None, speaker_encoder=None):
+        self.ctx, self.llm, self.flow, self.hifigan, self.s3, self.speaker_encoder = ctx, llm, flow, hifigan, s3_tokenizer, speaker_encoder
 
     # ---- prepareConditionals, tensor part (CosyVoice2TTS.swift:383-423) -------------------------------------------------------------
-    def prepare_conditionals(self, ref_wav: np.ndarray, speaker_embedding: np.ndarray, prompt_text=()):
-        """ref_wav: 24 kHz mono reference clip (at most 30 s are used, CosyVoice2TTS.swift:375-380)."""
+    def prepare_conditionals(self, ref_wav: np.ndarray, speaker_embedding: np.ndarray | None = None, prompt_text=()):
+        """ref_wav: 24 kHz mono reference clip (at most 30 s are used, CosyVoice2TTS.swift:375-380).  speaker_embedding None ->
+        speakerEncoder(audio16k) (CosyVoice2TTS.swift:409): the CAM++ embedding of the 16 kHz clip."""
         from . import audio as A
         if self.s3 is None:
             raise ValueError("CosyVoice2Model was built without an S3 tokenizer")
@@ -37,6 +38,10 @@ class CosyVoice2Model:
         mel80 = A.s3gen_mel_spectrogram(self.ctx, ref_wav_24k).T                       # [frames, 80]
         # the engine trims both so that mel frames == 2 * speech tokens (CosyVoice2TTS.swift:404-414)
         n = min(mel80.shape[0] // 2, toks.shape[0])
+        if speaker_embedding is None:
+            if self.speaker_encoder is None:
+                raise ValueError("CosyVoice2Model was built without a speaker encoder and no speaker_embedding was given")
+            speaker_embedding = self.speaker_encoder(ref_wav_16k)[0]
         return CosyVoice2Conditionals(toks[:n].copy(), np.ascontiguousarray(mel80[:2 * n]), np.ascontiguousarray(speaker_embedding, np.float32),
                                       list(prompt_text))
 

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
         else if (g.gelu == 3) v = fabsf(v);
         else if (g.gelu == 4) v = v / (1.0f + __expf(-v));
         else if (g.gelu == 5) v = v > 0.f ? v : 0.01f * v;
+        else if (g.gelu == 6) v = fmaxf(v, 0.f);
         if (g.noise) v = g.R[yr * g.ldr + n] + g.noise[yr] * v;
         else if (g.R) v += g.R[yr * g.ldr + n];
         if (g.out_scale != 0.f) v *= g.out_scale;

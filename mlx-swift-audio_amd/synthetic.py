@@ -564,3 +564,64 @@ def flow_weights(cfg: FlowConfig, seed: int = 0) -> dict[str, np.ndarray]:
     conv(d + ".final_block.conv.conv", C, 3, C); ln(d + ".final_block.norm", C)
     conv(d + ".final_proj", M, 1, C)
     return w
+
+
+# ---- CAM++ speaker encoder ----------------------------------------------------------------------------------------
+CAMPP_BLOCKS = ((12, 3, 1), (24, 3, 2), (16, 3, 2))      # (layers, kernel, dilation) of the three dense blocks (CAMPPlus.swift:722)
+
+
+def campplus_weights(seed: int = 0) -> dict[str, np.ndarray]:
+    """Random-init CAMPPlus tensors with the reference's Module key paths (CAMPPlus.swift:687-753; the configuration
+    CAMPlusSpeakerEncoder.swift:19-27 builds: 80 fbank bins, 192-d embedding, growth 32, bottleneck 128, 128 initial channels).
+    MLX layouts: Conv2d [O, KH, KW, I], Conv1d [O, K, I].  He-scaled convolutions and BatchNorm statistics near (0, 1) keep
+    every layer's activations O(1), so a wrong channel, tap or dilation shows up in the 192-d output."""
+    w: dict[str, np.ndarray] = {}
+
+    def rng_for(name):
+        return np.random.Generator(np.random.PCG64(_key_seed(name, seed)))
+
+    def conv(name, shape, bias=False):
+        fan_in = int(np.prod(shape[1:]))
+        w[name + ".weight"] = (rng_for(name + ".weight").standard_normal(shape, dtype=np.float32) * np.float32(math.sqrt(2.0 / fan_in)))
+        if bias:
+            w[name + ".bias"] = (0.1 * rng_for(name + ".bias").standard_normal(shape[0])).astype(np.float32)
+
+    def bn(name, c, affine=True):
+        r = rng_for(name)
+        if affine:
+            w[name + ".weight"] = (1.0 + 0.1 * r.standard_normal(c)).astype(np.float32)
+            w[name + ".bias"] = (0.1 * r.standard_normal(c)).astype(np.float32)
+        w[name + ".running_mean"] = (0.1 * r.standard_normal(c)).astype(np.float32)
+        w[name + ".running_var"] = (0.5 + r.random(c)).astype(np.float32)
+
+    m = 32
+    conv("head.conv1", (m, 3, 3, 1)); bn("head.bn1", m)
+    for layer in ("layer1", "layer2"):
+        for i, stride in ((0, 2), (1, 1)):
+            p = f"head.{layer}.{i}"
+            conv(p + ".conv1", (m, 3, 3, m)); bn(p + ".bn1", m)
+            conv(p + ".conv2", (m, 3, 3, m)); bn(p + ".bn2", m)
+            if stride != 1:
+                conv(p + ".shortcut.0", (m, 1, 1, m)); bn(p + ".shortcut.1", m)
+    conv("head.conv2", (m, 3, 3, m)); bn("head.bn2", m)
+    ch = m * (80 // 8)
+    conv("tdnn.linear", (128, 5, ch)); bn("tdnn.nonlinear.0", 128)
+    ch = 128
+    for b, (n_layers, k, _dil) in enumerate(CAMPP_BLOCKS):
+        for i in range(n_layers):
+            p = f"blocks.{b}.layers.{i}"
+            cin = ch + 32 * i
+            bn(p + ".nonlinear1.0", cin)
+            conv(p + ".linear1", (128, 1, cin))
+            bn(p + ".nonlinear2.0", 128)
+            conv(p + ".cam_layer.linear_local", (32, k, 128))
+            conv(p + ".cam_layer.linear1", (64, 1, 128), bias=True)
+            conv(p + ".cam_layer.linear2", (32, 1, 64), bias=True)
+        ch += 32 * n_layers
+        bn(f"transits.{b}.nonlinear.0", ch)
+        conv(f"transits.{b}.linear", (ch // 2, 1, ch))
+        ch //= 2
+    bn("out_nonlinear.0", ch)
+    conv("dense.linear", (192, 1, 2 * ch))
+    bn("dense.nonlinear.0", 192, affine=False)
+    return w

@@ -15,8 +15,8 @@ S_TOK = 6561
 def test_zero_shot_pipeline(ctx):
     import dataclasses
     import mlx_swift_audio_amd as m
-    from mlx_swift_audio_amd import cosyvoice2 as CV, flow as HF, hift as HH, lm as HL, s3tok as HS
-    from oracle import flow as OF, hift as OH, logmel as OL
+    from mlx_swift_audio_amd import cosyvoice2 as CV, flow as HF, hift as HH, lm as HL, s3tok as HS, speaker as SP
+    from oracle import campplus as OC, flow as OF, hift as OH, logmel as OL
 
     lcfg = S.LM_CONFIGS["qwen-micro"]
     lw = S.lm_weights(lcfg, seed=3, round_to="f16")
@@ -30,13 +30,17 @@ def test_zero_shot_pipeline(ctx):
     hift = HH.HiFTGenerator.load(ctx, hcfg, hw)
     scfg = S.S3_CONFIGS["s3_micro"]
     s3 = HS.S3Tokenizer.load(ctx, scfg, S.s3_weights(scfg, 3))
-    model = CV.CosyVoice2Model(ctx, llm, flow, hift, s3)
+    cw = S.campplus_weights(3)
+    spk_enc = SP.CAMPlusSpeakerEncoder.load(ctx, cw)
+    model = CV.CosyVoice2Model(ctx, llm, flow, hift, s3, spk_enc)
 
     # ---- conditionals from a 2 s, 24 kHz reference clip (resampled to 16 kHz on the device for the tokenizer)
     ref24 = OL.synth_clip(2, 48000)
     rng = np.random.default_rng(0)
-    spk = rng.standard_normal(fcfg.spk_embed_dim).astype(np.float32)
-    cond = model.prepare_conditionals(ref24, spk, prompt_text=[7, 8, 9])
+    cond = model.prepare_conditionals(ref24, prompt_text=[7, 8, 9])          # speaker embedding from the clip itself (CAM++)
+    from mlx_swift_audio_amd import audio as A
+    want_spk = OC.CAMPPlusOracle(cw).inference(A.resample_audio(ctx, ref24, 24000, 16000))[0]
+    assert np.abs(cond.speaker_embedding - want_spk).max() <= 3e-3 * np.abs(want_spk).max()
     n_p = cond.prompt_speech_token.shape[0]
     assert n_p == 50 and cond.prompt_mel.shape == (2 * n_p, 80)          # 2 s -> 50 tokens @ 25 Hz, 100 mel frames @ 50 Hz
     np.testing.assert_allclose(cond.prompt_mel, OL.s3gen_mel_spectrogram(ref24).T[:2 * n_p], atol=2e-3)
@@ -69,6 +73,6 @@ def test_zero_shot_pipeline(ctx):
     again, tokens2 = model.synthesize(text, cond, u, z_fn, noise_fn)
     assert tokens2 == tokens
     np.testing.assert_array_equal(again, audio)
-    for h in (flow, hift, s3):
+    for h in (flow, hift, s3, spk_enc):
         h.close()
     llm.lm.close()
