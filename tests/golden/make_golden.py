@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 from mlx_swift_audio_amd import synthetic as S  # noqa: E402
-from oracle import codec as OC, flow as OF, hift as OH, lm as OLM, logmel as OL, s3tok as OS, whisper as OW  # noqa: E402
+from oracle import campplus as OCP, codec as OC, flow as OF, hift as OH, lm as OLM, logmel as OL, s3tok as OS, whisper as OW  # noqa: E402
 
 
 def wsum(w, keys):
@@ -112,7 +112,18 @@ def lm():
                         wsum=wsum(w, ["model.embed_tokens.weight"]))
 
 
+def campplus():
+    w = S.campplus_weights(2)
+    clip = OL.synth_clip(8, 16000)[:12000]
+    fb = OCP.kaldi_fbank(clip)
+    np.savez_compressed(os.path.join(OUT, "campplus.npz"), clip=clip, fbank=fb, embedding=OCP.CAMPPlusOracle(w).inference(clip)[0],
+                        wsum=wsum(w, ["head.conv1.weight", "blocks.2.layers.15.cam_layer.linear_local.weight", "dense.linear.weight"]))
+
+
 if __name__ == "__main__":
-    for fn in (logmel, whisper, codecs, cosyvoice2, lm):
+    only = set(sys.argv[1:])
+    for fn in (logmel, whisper, codecs, cosyvoice2, lm, campplus):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print("wrote", fn.__name__)

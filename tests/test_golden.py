@@ -85,6 +85,15 @@ def test_oracle_lm_golden():
     np.testing.assert_allclose(np.asarray(logits[-1], np.float32), g["last_logits"], atol=2e-4)
 
 
+def test_oracle_campplus_golden():
+    from oracle import campplus as OCP
+    g = _load("campplus.npz")
+    w = S.campplus_weights(2)
+    np.testing.assert_allclose(_wsum(w, ["head.conv1.weight", "blocks.2.layers.15.cam_layer.linear_local.weight", "dense.linear.weight"]), g["wsum"], rtol=1e-12)
+    np.testing.assert_allclose(OCP.kaldi_fbank(g["clip"]), g["fbank"], atol=1e-4)
+    np.testing.assert_allclose(OCP.CAMPPlusOracle(w).inference(g["clip"])[0], g["embedding"], atol=2e-4 * np.abs(g["embedding"]).max())
+
+
 # ---- GPU: HIP path vs frozen ---------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_hip_logmel_golden(ctx):
@@ -166,3 +175,13 @@ def test_hip_lm_golden(ctx):
     logits = model.forward(g["ids"].tolist())
     np.testing.assert_allclose(np.asarray(logits, np.float32).reshape(-1), g["last_logits"], atol=0.03, rtol=0.02)
     model.close()
+
+
+@pytest.mark.gpu
+def test_hip_campplus_golden(ctx):
+    from mlx_swift_audio_amd import speaker as SP
+    g = _load("campplus.npz")
+    enc = SP.CAMPlusSpeakerEncoder.load(ctx, S.campplus_weights(2))
+    np.testing.assert_allclose(enc.extract_fbank(g["clip"]), g["fbank"], atol=2e-3)
+    assert np.abs(enc(g["clip"])[0] - g["embedding"]).max() <= 3e-3 * np.abs(g["embedding"]).max()
+    enc.close()
