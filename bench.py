@@ -185,8 +185,8 @@ def codec_bench(ctx, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="large-v3-turbo")
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
