@@ -1,0 +1,71 @@
+"""Full-size checks at BASELINE.json's shapes (random-init weights of the real architectures), beyond the micro-model parity suites:
+
+* Whisper large-v3-turbo (the headline configuration): one 30 s clip through log-mel -> 32-layer encoder -> greedy decode, HIP vs the
+  fp32 CPU oracle at full size (encoder features, first generated tokens, avg_logprob), plus the size-independent properties the
+  bench relies on: a clip's tokens do not depend on which batch it sits in, and repeated runs are bit-identical.
+* Qwen2-0.5B (CosyVoice2's LM backbone, 24 layers): last-position logits vs the oracle, batched prompt pass vs stepping.
+
+These take ~1 minute (checkpoint generation + a 4 s CPU encoder pass), hence one test each."""
+import numpy as np
+import pytest
+
+from mlx_swift_audio_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_whisper_large_v3_turbo_full_size(ctx):
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import whisper as HW
+    from oracle import logmel as OL
+    from oracle import whisper as OW
+    dims = S.DIMS["large-v3-turbo"]
+    weights = S.synthetic_weights(dims, seed=0, style="survey", round_to="bf16")      # one checkpoint for both sides
+    model = HW.WhisperModel.load(ctx, dims, weights, m.BF16)
+    n_new = 12
+    o = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(model.special), blank_ids=[220], max_new_tokens=n_new)
+    clips = [S.synth_clip(i) for i in range(4)]
+    solo = model.transcribe_windows(clips[:1], o)[0]
+    feats = model.audio_features()[0]                                  # [1500, 1280]
+    # ---- parity at full size against the CPU restatement (bf16-rounded weights and mel, fp32 arithmetic)
+    ora = OW.WhisperOracle(dims, weights)
+    mel = OW.round_array(OL.whisper_log_mel_spectrogram(clips[0], dims.n_mels, padding=OL.N_SAMPLES)[:OL.N_FRAMES], "bf16")[None]
+    xa = ora.encode(mel)
+    ref_feats = xa.numpy()[0]
+    scale = np.abs(ref_feats).max()
+    assert np.abs(feats - ref_feats).max() <= 0.03 * scale, (np.abs(feats - ref_feats).max(), scale)   # 32 bf16 layers, tolerance of test_whisper_gpu.py
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    ref = OW.greedy_decode(ora, st, xa, OW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=n_new))
+    # tokens agree up to the first step whose top-2 logit margin is within bf16 noise (the oracle records every step's margin)
+    k = next((i for i, (a, b) in enumerate(zip(solo.tokens, ref.tokens)) if a != b), min(len(solo.tokens), len(ref.tokens)))
+    assert k == len(ref.tokens) or ref.margins[k] < 0.05, (solo.tokens, ref.tokens, ref.margins)
+    if k == len(ref.tokens):                        # (NaN on both sides when a step had every token masked: the reference's own arithmetic)
+        assert (np.isnan(solo.avg_logprob) and np.isnan(ref.avg_logprob)) or abs(solo.avg_logprob - ref.avg_logprob) <= 0.02 * max(1.0, abs(ref.avg_logprob))
+    # ---- size-independent properties
+    batch = model.transcribe_windows(clips, o)
+    assert batch[0].tokens == solo.tokens                                                     # batch invariance (fixed-order sums)
+    assert np.array_equal(np.float32(batch[0].avg_logprob), np.float32(solo.avg_logprob), equal_nan=True)
+    again = model.transcribe_windows(clips, o)
+    assert [r.tokens for r in again] == [r.tokens for r in batch]                             # determinism
+    assert all(len(r.tokens) == n_new for r in batch)                                          # random weights never emit EOT early
+    model.close()
+
+
+def test_qwen2_half_billion_full_size(ctx):
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    from oracle import lm as OLM
+    cfg = S.LM_CONFIGS["qwen2-0.5b"]
+    w = S.lm_weights(cfg, seed=0, round_to="bf16")
+    model = HL.CausalLM.load(ctx, cfg, w, m.BF16)
+    ids = np.random.default_rng(0).integers(0, cfg.vocab, 24).tolist()
+    got = model.forward(ids)                                           # 23 positions through the batched prompt pass + one step
+    ref = OLM.LMOracle(cfg, w).forward(ids).numpy()[-1]
+    assert np.abs(got - ref).max() <= 0.08 * ref.std(), (np.abs(got - ref).max(), ref.std())
+    model.reset()
+    for t in ids[:-1]:
+        model.forward([t])
+    stepped = model.forward([ids[-1]])
+    assert np.abs(stepped - ref).max() <= 0.08 * ref.std()
+    assert np.abs(got - stepped).max() <= 0.05 * ref.std()           # two fp32 summation orders in front of the same 16-bit roundings, 24 layers deep
+    model.close()
