@@ -299,6 +299,14 @@ int mia_lm_forward(mia_lm* lm, const int32_t* ids, int n, float* last_logits);
  * over the kept tokens in index order).  Host pointers. */
 int mia_lm_generate(mia_lm* lm, const int32_t* prompt, int n_prompt, const mia_lm_sampler* sampler, const float* uniforms,
                     int32_t* out_tokens, int32_t* n_out);
+/* Sentence-level batching (MI355X-side addition; the reference generates its sentences one after another, OrpheusTTS.swift:179-191):
+ * mia_lm_set_batch sizes the per-sequence state (K/V caches, repetition windows, ...) for up to max_batch <= 32 sequences;
+ * mia_lm_generate_batch runs mia_lm_generate's loop for n_seq prompts side by side -- one read of the weights per step for all of
+ * them.  prompts: all ids back to back, prompt_offsets [n_seq + 1]; uniforms [n_seq][max_new_tokens]; out_tokens
+ * [n_seq][max_new_tokens]; n_out [n_seq].  Sequence b's output equals mia_lm_generate(prompt b, uniforms row b).  Host pointers. */
+int mia_lm_set_batch(mia_lm* lm, int max_batch);
+int mia_lm_generate_batch(mia_lm* lm, const int32_t* prompts, const int32_t* prompt_offsets, int n_seq, const mia_lm_sampler* sampler,
+                          const float* uniforms, int32_t* out_tokens, int32_t* n_out);
 /* CosyVoice2 RAS sampling parameters (TTS/CosyVoice2/LLM/Qwen2LM.swift:433-488 defaults: top_p 0.8, top_k 25, win 10, tau 0.1;
  * eos = speech_token_size (6561); min_len / max_len = 2x / 20x the text length, :368-372). */
 typedef struct { float top_p; int32_t top_k; int32_t win; float tau; int32_t eos; int32_t min_len; int32_t max_len; } mia_ras_params;

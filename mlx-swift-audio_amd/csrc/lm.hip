@@ -64,6 +64,11 @@ struct mia_lm {
   int S_qkv = 1, S_o = 1, S_down = 1;
   // batched prompt pass (lm_prefill): row buffers for one chunk of PF_ROWS positions, allocated on first use
   char* pf_buf = nullptr;
+  // sequences decoded side by side (mia_lm_set_batch): every state buffer above holds B_cap rows / caches; the single-sequence entry
+  // points use row 0
+  int B_cap = 1;
+  int graph_nb = 0;
+  std::vector<void*> state_allocs;
 };
 
 namespace {
@@ -95,14 +100,17 @@ __device__ __forceinline__ void rms_store(const f32x4 (&v)[LM_NV], int nv, int D
 }
 
 // x = E[token[pos]] (or a caller-provided embedding row);  h = RMSNorm(x) * w
-// One workgroup per row.  The step graph runs one row at st->pos (pos0 < 0); the batched prompt pass runs rows pos0 + blockIdx.x.
+// One workgroup per row.  Step graph (pos0 < 0): row b is SEQUENCE b at its own st[b].pos (tokens / embedding rows / state strided per
+// sequence); batched prompt pass (pos0 >= 0): rows are positions pos0 + blockIdx.x of the one sequence the pointers address.
 template <typename T>
 __global__ __launch_bounds__(256) void lm_embed_norm(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ emb, const uint16_t* __restrict__ gen_emb,
                                                      const float* __restrict__ embeds, const float* __restrict__ w,
-                                                     float* __restrict__ x, uint16_t* __restrict__ h, const LmState* __restrict__ st, int D, float eps, int pos0) {
+                                                     float* __restrict__ x, uint16_t* __restrict__ h, const LmState* __restrict__ st, int D, float eps, int pos0,
+                                                     int max_ctx) {
   __shared__ float sh[4];
   const int tid = threadIdx.x, nv = D >> 2;
-  const int pos = (pos0 < 0 ? st->pos : pos0) + (int)blockIdx.x;
+  if (pos0 < 0) { st += blockIdx.x; tokens += (int64_t)blockIdx.x * max_ctx; embeds += (int64_t)blockIdx.x * max_ctx * D; }
+  const int pos = pos0 < 0 ? st->pos : pos0 + (int)blockIdx.x;
   x += (int64_t)blockIdx.x * D; h += (int64_t)blockIdx.x * D;
   const bool from_rows = pos < st->n_embeds;               // prompt given as embedding rows
   const int tok = from_rows ? 0 : tokens[pos];
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void lm_embed_norm(const int32_t* __restrict__
 // x += sum_s partial[s];  h = RMSNorm(x) * w        (one workgroup per row; the batched prompt pass runs it with S = 0)
 template <typename T>
 __global__ __launch_bounds__(256) void lm_reduce_norm(const float* __restrict__ partial, int S, const float* __restrict__ w, float* __restrict__ x,
-                                                      uint16_t* __restrict__ h, int D, float eps) {
+                                                      uint16_t* __restrict__ h, int D, float eps, int B) {
   __shared__ float sh[4];
   const int tid = threadIdx.x, nv = D >> 2;
   x += (int64_t)blockIdx.x * D; h += (int64_t)blockIdx.x * D;
@@ -142,7 +150,8 @@ __global__ __launch_bounds__(256) void lm_reduce_norm(const float* __restrict__ 
       // slice S-1 and is discarded, so the loads are unconditional and the sum keeps its fixed order.
       f32x4 p[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) p[k] = S > 0 ? *reinterpret_cast<const f32x4*>(partial + (int64_t)(k < S ? k : S - 1) * D + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < 8; ++k)                        // slices are [S][B][D]: row blockIdx.x of each
+        p[k] = S > 0 ? *reinterpret_cast<const f32x4*>(partial + ((int64_t)(k < S ? k : S - 1) * B + blockIdx.x) * D + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (k < S) {
@@ -207,8 +216,10 @@ constexpr int ATT_NW = 16;
 template <typename T, int DH, bool FUSED>
 __global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __restrict__ q, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
                                                     uint16_t* __restrict__ out, const LmState* __restrict__ st, int Hq, int Hkv, int max_ctx, float scale, int pos0,
-                                                    const float* __restrict__ part, int S, const float* __restrict__ bias, const float* __restrict__ inv_freq) {
+                                                    const float* __restrict__ part, int S, const float* __restrict__ bias, const float* __restrict__ inv_freq,
+                                                    int B, int64_t seq_stride) {
   extern __shared__ float sc[];            // [max_ctx] scores, then red[ATT_NW][DH] + red2[2 * ATT_NW] (+ FUSED: q, k, v rows [3][DH])
+  if (FUSED) { st += blockIdx.y; kc += (int64_t)blockIdx.y * seq_stride; vc += (int64_t)blockIdx.y * seq_stride; }   // row = sequence
   constexpr int LPK = DH / 8;              // lanes per key
   constexpr int KPW = 64 / LPK;            // keys per wave instruction
   float* red = sc + max_ctx;
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __re
   float* vn = kn + DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, kvh = h / (Hq / Hkv);
-  const int nk = (pos0 < 0 ? st->pos : pos0) + (int)blockIdx.y + 1;
+  const int nk = FUSED ? st->pos + 1 : pos0 + (int)blockIdx.y + 1;
   const int nkc = FUSED ? nk - 1 : nk;     // keys read from the cache
   q += (int64_t)blockIdx.y * Hq * DH; out += (int64_t)blockIdx.y * Hq * DH;
   const int c = lane % LPK, g = lane / LPK;
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __re
     auto val = [&](int n) {                // S <= 4 slices, loads issued together
       float pv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pv[k] = part[(int64_t)(k < S ? k : S - 1) * N + n];
+      for (int k = 0; k < 4; ++k) pv[k] = part[((int64_t)(k < S ? k : S - 1) * B + blockIdx.y) * N + n];   // slices [S][B][N]
       float a = bias ? bias[n] : 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) if (k < S) a += pv[k];
@@ -404,6 +415,8 @@ __device__ __forceinline__ V blk1024_excl_scan(V v, V* sh) {
 
 __global__ __launch_bounds__(1024) void lm_sample(float* __restrict__ logits, int V, int32_t* __restrict__ tokens, int32_t* __restrict__ hist,
                                                   const float* __restrict__ uniforms, LmState* __restrict__ st, mia_lm_sampler sp, int n_prompt_arg, int max_ctx) {
+  // one workgroup per sequence
+  st += blockIdx.x; logits += (int64_t)blockIdx.x * V; tokens += (int64_t)blockIdx.x * max_ctx; hist += blockIdx.x * 64; uniforms += (int64_t)blockIdx.x * max_ctx;
   const int n_prompt = n_prompt_arg < 0 ? st->n_prompt : n_prompt_arg;      // the step graph reads it from the state: one graph serves every prompt length
   extern __shared__ unsigned long long hbin[];                               // per-copy bins, layout per level (see above)
   __shared__ double shd[16];
@@ -640,10 +653,11 @@ __global__ __launch_bounds__(1024) void lm_sample(float* __restrict__ logits, in
 }
 
 // lm_sample needs 128 KB of dynamic LDS: raise the kernel's limit once per process
-int lm_sample_launch(hipStream_t s, float* logits, int V, int32_t* tokens, int32_t* hist, const float* uniforms, LmState* st, const mia_lm_sampler& sp, int n_prompt, int max_ctx) {
+int lm_sample_launch(hipStream_t s, float* logits, int V, int32_t* tokens, int32_t* hist, const float* uniforms, LmState* st, const mia_lm_sampler& sp, int n_prompt, int max_ctx,
+                     int B = 1) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lm_sample), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMP_LDS_BYTES);
   if (attr != hipSuccess) return -1;
-  hipLaunchKernelGGL(lm_sample, dim3(1), dim3(1024), SMP_LDS_BYTES, s, logits, V, tokens, hist, uniforms, st, sp, n_prompt, max_ctx);
+  hipLaunchKernelGGL(lm_sample, dim3(B), dim3(1024), SMP_LDS_BYTES, s, logits, V, tokens, hist, uniforms, st, sp, n_prompt, max_ctx);
   return 0;
 }
 
@@ -784,7 +798,7 @@ __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ 
 }
 
 // greedy / plain path: advance only (logits are read back by the host)
-__global__ void lm_advance(LmState* st) { st->pos += 1; }
+__global__ void lm_advance(LmState* st) { st[blockIdx.x].pos += 1; }
 __global__ void lm_set_pos(LmState* st, int pos) { st->pos = pos; }
 
 // batched prompt pass: act[r][j] = silu(gu[r][2j]) * gu[r][2j+1] from the fp32 GEMM output (same expression as the SK_SWIGLU epilogue)
@@ -845,13 +859,15 @@ int pick_split(int K, int want) { for (int s = want; s > 1; --s) if (K % (32 * s
 
 // one launch site for the eight (dtype, head_dim, fused) instances
 int lm_launch_attention(mia_lm* m, bool fused, int rows, const void* q, uint16_t* kc, uint16_t* vc, void* att, int pos0, const float* part, int S, const float* bias) {
+  // fused: rows = sequences (row b uses state b and the b-th cache of the layer); otherwise rows = positions of one sequence
+  const int64_t seq_stride = (int64_t)m->cfg.n_kv_heads * m->cfg.max_ctx * m->cfg.head_dim;
   const mia_lm_config& c = m->cfg;
   hipStream_t s = m->ctx->stream;
   const int dh = c.head_dim;
   const size_t lds = (size_t)(c.max_ctx + ATT_NW * dh + 2 * ATT_NW + 3 * dh) * 4;
   const float scale = 1.0f / sqrtf((float)dh);
   const dim3 grid(c.n_heads, rows), block(64 * ATT_NW);
-#define ATT_GO(TT, DD, FF) hipLaunchKernelGGL((lm_attention<TT, DD, FF>), grid, block, lds, s, (const uint16_t*)q, kc, vc, (uint16_t*)att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, pos0, part, S, bias, m->inv_freq)
+#define ATT_GO(TT, DD, FF) hipLaunchKernelGGL((lm_attention<TT, DD, FF>), grid, block, lds, s, (const uint16_t*)q, kc, vc, (uint16_t*)att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, pos0, part, S, bias, m->inv_freq, rows, seq_stride)
   const bool f16 = m->dtype == MIA_F16;
   if (dh == 128) { if (fused) { if (f16) ATT_GO(F16, 128, true); else ATT_GO(BF16, 128, true); } else { if (f16) ATT_GO(F16, 128, false); else ATT_GO(BF16, 128, false); } }
   else           { if (fused) { if (f16) ATT_GO(F16, 64, true); else ATT_GO(BF16, 64, true); } else { if (f16) ATT_GO(F16, 64, false); else ATT_GO(BF16, 64, false); } }
@@ -859,35 +875,37 @@ int lm_launch_attention(mia_lm* m, bool fused, int rows, const void* q, uint16_t
   return 0;
 }
 
-int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_prompt, const RasParams* ras = nullptr) {
+int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_prompt, const RasParams* ras = nullptr, int nb = 1) {
   hipStream_t s = m->ctx->stream;
   const mia_lm_config& c = m->cfg;
   const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh, Nqkv = Nq + 2 * Nk;
   const bool f16 = m->dtype == MIA_F16;
+  // nb sequences = nb rows of every skinny GEMM: the weights are still read once per step
   auto skinny = [&](const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int N, int K, int S, int mode) {
-    SkinnyArgs a{(const uint16_t*)A, lda, (const uint16_t*)W, bias, out, ldo, nullptr, nullptr, nullptr, 1, N, K, S, MIA_ACT_NONE, 0, 0, 0};
+    SkinnyArgs a{(const uint16_t*)A, lda, (const uint16_t*)W, bias, out, ldo, nullptr, nullptr, nullptr, nb, N, K, S, MIA_ACT_NONE, 0, 0, 0};
     return skinny_gemm_launch(a, mode, m->dtype, s);
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
-  LAUNCH_T(lm_embed_norm, dim3(1), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps, -1);
+  LAUNCH_T(lm_embed_norm, dim3(nb), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps, -1, c.max_ctx);
+  const size_t layer_stride = (size_t)m->B_cap * c.n_kv_heads * c.max_ctx * dh;
   for (int l = 0; l < c.n_layers; ++l) {
     const LmLayer& L = m->layers[l];
-    uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * c.n_kv_heads * c.max_ctx * dh;
-    uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * c.n_kv_heads * c.max_ctx * dh;
+    uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * layer_stride;
+    uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * layer_stride;
     if (skinny(m->h, D, L.wqkv, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL)) return -1;
-    lm_launch_attention(m, true, 1, nullptr, kc, vc, m->att, -1, m->qkv_part, m->S_qkv, L.bqkv);      // RoPE + cache row + attention
+    lm_launch_attention(m, true, nb, nullptr, kc, vc, m->att, -1, m->qkv_part, m->S_qkv, L.bqkv);      // RoPE + cache row + attention
     if (skinny(m->att, Nq, L.wo, nullptr, m->partial, 0, D, Nq, m->S_o, SK_PARTIAL)) return -1;
-    LAUNCH_T(lm_reduce_norm, dim3(1), dim3(256), 0, m->partial, m->S_o, L.post_norm, m->x, (uint16_t*)m->h, D, c.rms_eps);
+    LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_o, L.post_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
     if (skinny(m->h, D, L.wgu, nullptr, m->act, c.inter, 2 * c.inter, D, 1, SK_SWIGLU)) return -1;
     if (skinny(m->act, c.inter, L.wdown, nullptr, m->partial, 0, D, c.inter, m->S_down, SK_PARTIAL)) return -1;
-    LAUNCH_T(lm_reduce_norm, dim3(1), dim3(256), 0, m->partial, m->S_down, l + 1 < c.n_layers ? m->layers[l + 1].in_norm : m->final_norm, m->x, (uint16_t*)m->h, D, c.rms_eps);
+    LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_down, l + 1 < c.n_layers ? m->layers[l + 1].in_norm : m->final_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
   }
 #undef LAUNCH_T
   const int HV = m->head_vocab > 0 ? m->head_vocab : c.vocab;
   if (skinny(m->h, D, m->lm_head, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32)) return -1;
   if (ras) hipLaunchKernelGGL(lm_sample_ras, dim3(1), dim3(1024), 0, s, m->logits, HV, m->tokens, m->out_tokens, m->uniforms, m->state, *ras, c.max_ctx);
-  else if (sampling) { if (lm_sample_launch(s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx)) return -1; }
-  else hipLaunchKernelGGL(lm_advance, dim3(1), dim3(1), 0, s, m->state);
+  else if (sampling) { if (lm_sample_launch(s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx, nb)) return -1; }
+  else hipLaunchKernelGGL(lm_advance, dim3(nb), dim3(1), 0, s, m->state);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -908,7 +926,7 @@ bool lm_prefill_supported(const mia_lm* m) {
   return !off && c.hidden % 64 == 0 && (c.n_heads * c.head_dim) % 64 == 0 && c.inter % 64 == 0;
 }
 
-int lm_prefill(mia_lm* m, int pos0, int P) {
+int lm_prefill(mia_lm* m, int pos0, int P, int seq = 0) {
   mia_ctx* ctx = m->ctx;
   hipStream_t s = ctx->stream;
   const mia_lm_config& c = m->cfg;
@@ -939,49 +957,82 @@ int lm_prefill(mia_lm* m, int pos0, int P) {
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
   for (int r0 = 0; r0 < P; r0 += PF_ROWS) {
     const int M = std::min(PF_ROWS, P - r0), p0 = pos0 + r0;
-    LAUNCH_T(lm_embed_norm, dim3(M), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, x, h, m->state, D, c.rms_eps, p0);
+    LAUNCH_T(lm_embed_norm, dim3(M), dim3(256), 0, m->tokens + (size_t)seq * c.max_ctx, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed,
+             m->embeds + (size_t)seq * c.max_ctx * D, m->layers[0].in_norm, x, h, m->state + seq, D, c.rms_eps, p0, c.max_ctx);
     for (int l = 0; l < c.n_layers; ++l) {
       const LmLayer& L = m->layers[l];
-      uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * c.n_kv_heads * c.max_ctx * dh;
-      uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * c.n_kv_heads * c.max_ctx * dh;
+      uint16_t* kc = (uint16_t*)m->k_cache + ((size_t)l * m->B_cap + seq) * c.n_kv_heads * c.max_ctx * dh;
+      uint16_t* vc = (uint16_t*)m->v_cache + ((size_t)l * m->B_cap + seq) * c.n_kv_heads * c.max_ctx * dh;
       if (gemm(h, D, L.wqkv, nullptr, qkv, Nqkv, M, nullptr)) return MIA_ERR_DEVICE;
       const int n_el = (c.n_heads + c.n_kv_heads) * (dh / 2) + Nk;
-      LAUNCH_T(lm_rope_cache, dim3((n_el + 255) / 256, M), dim3(256), 0, qkv, 1, L.bqkv, m->inv_freq, q, kc, vc, m->state, c.n_heads, c.n_kv_heads, dh, c.max_ctx, p0);
+      LAUNCH_T(lm_rope_cache, dim3((n_el + 255) / 256, M), dim3(256), 0, qkv, 1, L.bqkv, m->inv_freq, q, kc, vc, m->state + seq, c.n_heads, c.n_kv_heads, dh, c.max_ctx, p0);
       if (l + 1 == c.n_layers) break;            // past its K/V rows the last layer feeds only the head, which the prompt pass skips
       lm_launch_attention(m, false, M, q, kc, vc, att, p0, nullptr, 0, nullptr);
       if (gemm(att, Nq, L.wo, nullptr, x, D, M, x)) return MIA_ERR_DEVICE;                // x += att . Wo^T
-      LAUNCH_T(lm_reduce_norm, dim3(M), dim3(256), 0, (const float*)nullptr, 0, L.post_norm, x, h, D, c.rms_eps);
+      LAUNCH_T(lm_reduce_norm, dim3(M), dim3(256), 0, (const float*)nullptr, 0, L.post_norm, x, h, D, c.rms_eps, 1);
       if (gemm(h, D, L.wgu, nullptr, gu, 2 * I, M, nullptr)) return MIA_ERR_DEVICE;
       const int64_t n2 = (int64_t)M * I / 2;
       LAUNCH_T(lm_swiglu_rows, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, gu, act, n2);
       if (gemm(act, I, L.wdown, nullptr, x, D, M, x)) return MIA_ERR_DEVICE;              // x += act . Wdown^T
-      LAUNCH_T(lm_reduce_norm, dim3(M), dim3(256), 0, (const float*)nullptr, 0, m->layers[l + 1].in_norm, x, h, D, c.rms_eps);
+      LAUNCH_T(lm_reduce_norm, dim3(M), dim3(256), 0, (const float*)nullptr, 0, m->layers[l + 1].in_norm, x, h, D, c.rms_eps, 1);
     }
   }
 #undef LAUNCH_T
-  hipLaunchKernelGGL(lm_set_pos, dim3(1), dim3(1), 0, s, m->state, pos0 + P);
+  hipLaunchKernelGGL(lm_set_pos, dim3(1), dim3(1), 0, s, m->state + seq, pos0 + P);
   if (hipGetLastError() != hipSuccess) return mia_fail(ctx, MIA_ERR_DEVICE, "lm: prompt-pass launch failed");
   return MIA_OK;
 }
 
-int lm_graph(mia_lm* m, int mode, const mia_lm_sampler& sp, const RasParams* ras = nullptr) {
+int lm_graph(mia_lm* m, int mode, const mia_lm_sampler& sp, const RasParams* ras = nullptr, int nb = 1) {
   mia_ctx* ctx = m->ctx;
   static const bool no_graph = getenv("MIA_NO_GRAPH") != nullptr;
   if (no_graph) return 1;
   mia_lm_sampler key{}; RasParams rkey{};
   if (mode == 1) key = sp;
   if (mode == 2) rkey = *ras;
-  if (m->graph && m->graph_mode == mode && memcmp(&m->graph_sampler, &key, sizeof(key)) == 0 && memcmp(&m->graph_ras, &rkey, sizeof(rkey)) == 0) return 0;
+  if (m->graph && m->graph_mode == mode && m->graph_nb == nb && memcmp(&m->graph_sampler, &key, sizeof(key)) == 0 && memcmp(&m->graph_ras, &rkey, sizeof(rkey)) == 0) return 0;
   if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
   hipGraph_t g = nullptr;
   MIA_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  const int erc = lm_enqueue_step(m, mode != 0, sp, -1, mode == 2 ? ras : nullptr);
+  const int erc = lm_enqueue_step(m, mode != 0, sp, -1, mode == 2 ? ras : nullptr, nb);
   hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
   if (erc != 0 || ce != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return mia_fail(ctx, MIA_ERR_DEVICE, "lm: step graph capture failed"); }
   hipError_t ie = hipGraphInstantiate(&m->graph, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
   if (ie != hipSuccess) { m->graph = nullptr; return mia_fail(ctx, MIA_ERR_DEVICE, "lm: hipGraphInstantiate failed"); }
-  m->graph_sampler = key; m->graph_ras = rkey; m->graph_mode = mode;
+  m->graph_sampler = key; m->graph_ras = rkey; m->graph_mode = mode; m->graph_nb = nb;
+  return 0;
+}
+
+}  // namespace
+
+namespace {
+
+// every per-sequence buffer, for B sequences side by side (rows of the skinny GEMMs; caches [L][B][Hkv][max_ctx][dh])
+int lm_alloc_state(mia_lm* m, int B) {
+  const mia_lm_config& c = m->cfg;
+  const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh;
+  for (void* p : m->state_allocs) (void)hipFree(p);
+  m->state_allocs.clear();
+  if (m->graph) { (void)hipGraphExecDestroy(m->graph); m->graph = nullptr; }
+  bool ok = true;
+  auto dev = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes + 64) != hipSuccess) { ok = false; return nullptr; }
+    m->state_allocs.push_back(p);
+    return p;
+  };
+  const size_t kv = (size_t)c.n_layers * B * c.n_kv_heads * c.max_ctx * dh * 2;
+  m->k_cache = dev(kv); m->v_cache = dev(kv);
+  m->x = (float*)dev((size_t)B * D * 4); m->h = dev((size_t)B * D * 2);
+  m->qkv_part = (float*)dev((size_t)4 * B * (Nq + 2 * Nk) * 4); m->q = dev((size_t)B * Nq * 2); m->att = dev((size_t)B * Nq * 2); m->act = dev((size_t)B * c.inter * 2);
+  m->partial = (float*)dev((size_t)8 * B * D * 4); m->logits = (float*)dev((size_t)B * std::max(c.vocab, m->head_vocab) * 4);
+  m->tokens = (int32_t*)dev((size_t)B * c.max_ctx * 4); m->hist = (int32_t*)dev((size_t)B * 64 * 4); m->uniforms = (float*)dev((size_t)B * c.max_ctx * 4);
+  m->state = (LmState*)dev(sizeof(LmState) * B);
+  m->embeds = (float*)dev((size_t)c.max_ctx * D * 4); m->out_tokens = (int32_t*)dev((size_t)c.max_ctx * 4);     // RAS path: one sequence
+  if (!ok) return -1;
+  (void)hipMemset(m->k_cache, 0, kv); (void)hipMemset(m->v_cache, 0, kv); (void)hipMemset(m->state, 0, sizeof(LmState) * B);
+  m->B_cap = B;
   return 0;
 }
 
@@ -993,6 +1044,7 @@ extern "C" void mia_lm_free(mia_lm* m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   if (m->graph) (void)hipGraphExecDestroy(m->graph);
   for (void* p : m->allocs) (void)hipFree(p);
+  for (void* p : m->state_allocs) (void)hipFree(p);
   delete m;
 }
 
@@ -1072,16 +1124,7 @@ extern "C" mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia
   }
   if (!L.err.empty()) return fail(m, L.err);
   m->S_qkv = pick_split(D, 4); m->S_o = pick_split(Nq, 4); m->S_down = pick_split(c.inter, 8);
-  const size_t kv = (size_t)c.n_layers * c.n_kv_heads * c.max_ctx * dh * 2;
-  m->k_cache = L.dev(kv); m->v_cache = L.dev(kv);
-  m->x = (float*)L.dev((size_t)D * 4); m->h = L.dev((size_t)D * 2);
-  m->qkv_part = (float*)L.dev((size_t)4 * (Nq + 2 * Nk) * 4); m->q = L.dev((size_t)Nq * 2); m->att = L.dev((size_t)Nq * 2); m->act = L.dev((size_t)c.inter * 2);
-  m->partial = (float*)L.dev((size_t)8 * D * 4); m->logits = (float*)L.dev((size_t)std::max(c.vocab, m->head_vocab) * 4);
-  m->tokens = (int32_t*)L.dev((size_t)c.max_ctx * 4); m->hist = (int32_t*)L.dev(64 * 4); m->uniforms = (float*)L.dev((size_t)c.max_ctx * 4);
-  m->state = (LmState*)L.dev(sizeof(LmState));
-  m->embeds = (float*)L.dev((size_t)c.max_ctx * D * 4); m->out_tokens = (int32_t*)L.dev((size_t)c.max_ctx * 4);
-  if (!L.err.empty()) return fail(m, L.err);
-  (void)hipMemset(m->k_cache, 0, kv); (void)hipMemset(m->v_cache, 0, kv); (void)hipMemset(m->state, 0, sizeof(LmState));
+  if (lm_alloc_state(m, 1)) return fail(m, "hipMalloc failed (state buffers)");
   if (hipDeviceSynchronize() != hipSuccess) return fail(m, "device error during upload");
   return m;
 }
@@ -1160,6 +1203,83 @@ extern "C" int mia_lm_generate(mia_lm* m, const int32_t* prompt, int n_prompt, c
   MIA_HIP(ctx, hipStreamSynchronize(s));
   *n_out = st.n_gen;
   MIA_HIP(ctx, hipMemcpyAsync(out_tokens, m->tokens + n_prompt, (size_t)st.n_gen * 4, hipMemcpyDeviceToHost, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  return MIA_OK;
+}
+
+// Sequences side by side: every step reads the weights once for all of them (rows of the same skinny GEMMs), each sequence has
+// its own K/V cache, repetition window, uniforms and stop state.  Re-allocates the per-sequence state; 1 restores the default.
+extern "C" int mia_lm_set_batch(mia_lm* m, int max_batch) {
+  if (!m) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = m->ctx;
+  MIA_CHECK_ARG(ctx, max_batch >= 1 && max_batch <= 32, "lm_set_batch: 1 <= max_batch <= 32 (one MFMA row tile)");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (max_batch == m->B_cap) return MIA_OK;
+  if (lm_alloc_state(m, max_batch)) return mia_fail(ctx, MIA_ERR_OUT_OF_MEMORY, "lm_set_batch: state buffers for %d sequences", max_batch);
+  MIA_HIP(ctx, hipDeviceSynchronize());
+  return MIA_OK;
+}
+
+// mia_lm_generate for n_seq independent prompts at once (sentence-level batching of OrpheusTTS.generate, OrpheusTTS.swift:179-191: the
+// reference runs its sentences one after another).  prompts: the ids of all sequences back to back, prompt_offsets [n_seq + 1];
+// uniforms [n_seq][max_new_tokens]; out_tokens [n_seq][max_new_tokens]; n_out [n_seq].  Sequence b's ids equal what mia_lm_generate
+// returns for prompt b with uniforms row b (rows of a GEMM do not mix; asserted in tests/test_lm_gpu.py).
+extern "C" int mia_lm_generate_batch(mia_lm* m, const int32_t* prompts, const int32_t* prompt_offsets, int n_seq, const mia_lm_sampler* sp,
+                                     const float* uniforms, int32_t* out_tokens, int32_t* n_out) {
+  if (!m) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = m->ctx;
+  MIA_CHECK_ARG(ctx, prompts && prompt_offsets && sp && uniforms && out_tokens && n_out, "lm_generate_batch: null arguments");
+  MIA_CHECK_ARG(ctx, n_seq >= 1 && n_seq <= m->B_cap, "lm_generate_batch: n_seq %d exceeds the batch set with mia_lm_set_batch (%d)", n_seq, m->B_cap);
+  MIA_CHECK_ARG(ctx, sp->max_new_tokens > 0 && sp->rep_window >= 0 && sp->rep_window <= 64 && sp->n_stop >= 0 && sp->n_stop <= 4, "lm_generate_batch: bad sampler");
+  const int C = m->cfg.max_ctx, mn = sp->max_new_tokens;
+  int min_prompt = C;
+  for (int b = 0; b < n_seq; ++b) {
+    const int np_ = prompt_offsets[b + 1] - prompt_offsets[b];
+    MIA_CHECK_ARG(ctx, np_ > 0 && np_ + mn <= C, "lm_generate_batch: prompt %d: length %d + max_new_tokens exceeds max_ctx", b, np_);
+    for (int i = prompt_offsets[b]; i < prompt_offsets[b + 1]; ++i) MIA_CHECK_ARG(ctx, prompts[i] >= 0 && prompts[i] < m->cfg.vocab, "lm_generate_batch: token %d out of vocabulary", prompts[i]);
+    min_prompt = std::min(min_prompt, np_);
+  }
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  std::vector<LmState> st(n_seq);
+  for (int b = 0; b < n_seq; ++b) {
+    const int np_ = prompt_offsets[b + 1] - prompt_offsets[b];
+    st[b] = LmState{}; st[b].n_prompt = np_;
+    MIA_HIP(ctx, hipMemcpyAsync(m->tokens + (size_t)b * C, prompts + prompt_offsets[b], (size_t)np_ * 4, hipMemcpyHostToDevice, s));
+    MIA_HIP(ctx, hipMemcpyAsync(m->uniforms + (size_t)b * C, uniforms + (size_t)b * mn, (size_t)mn * 4, hipMemcpyHostToDevice, s));
+  }
+  MIA_HIP(ctx, hipMemcpyAsync(m->state, st.data(), sizeof(LmState) * n_seq, hipMemcpyHostToDevice, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  const int gr = lm_graph(m, 1, *sp, nullptr, n_seq);
+  if (gr < 0) return gr;
+  // prompts: everything but each prompt's last position through the batched prompt pass, sequence by sequence; when that path is
+  // not available every sequence walks its prompt in the step graph (the sampler idles until its own prompt is consumed)
+  const bool pre = lm_prefill_supported(m);
+  int first_steps = 0;
+  for (int b = 0; b < n_seq; ++b) {
+    const int np_ = st[b].n_prompt;
+    if (pre && np_ - 1 >= 1) { if (const int rc = lm_prefill(m, 0, np_ - 1, b)) return rc; }
+    else first_steps = std::max(first_steps, np_ - 1);
+  }
+  const int total = first_steps + mn;
+  for (int step = 0; step < total; ++step) {
+    if (gr == 0) MIA_HIP(ctx, hipGraphLaunch(m->graph, s));
+    else if (lm_enqueue_step(m, true, *sp, -1, nullptr, n_seq)) return mia_fail(ctx, MIA_ERR_DEVICE, "lm_generate_batch: launch failed");
+    if ((step & 15) == 15) {
+      MIA_HIP(ctx, hipMemcpyAsync(st.data(), m->state, sizeof(LmState) * n_seq, hipMemcpyDeviceToHost, s));
+      MIA_HIP(ctx, hipStreamSynchronize(s));
+      bool all = true;
+      for (int b = 0; b < n_seq; ++b) all = all && st[b].finished;
+      if (all) break;
+    }
+  }
+  MIA_HIP(ctx, hipMemcpyAsync(st.data(), m->state, sizeof(LmState) * n_seq, hipMemcpyDeviceToHost, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  for (int b = 0; b < n_seq; ++b) {
+    n_out[b] = st[b].n_gen;
+    if (st[b].n_gen > 0) MIA_HIP(ctx, hipMemcpyAsync(out_tokens + (size_t)b * mn, m->tokens + (size_t)b * C + st[b].n_prompt, (size_t)st[b].n_gen * 4, hipMemcpyDeviceToHost, s));
+  }
   MIA_HIP(ctx, hipStreamSynchronize(s));
   return MIA_OK;
 }

@@ -107,6 +107,45 @@ class CausalLM:
         return out[:n.value].tolist()
 
 
+def _declare_batch(lib):
+    if not getattr(lib, "_lm_batch_declared", False):
+        lib.mia_lm_set_batch.restype = C.c_int
+        lib.mia_lm_set_batch.argtypes = [C.c_void_p, C.c_int]
+        lib.mia_lm_generate_batch.restype = C.c_int
+        lib.mia_lm_generate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Sampler), C.c_void_p, C.c_void_p, C.c_void_p]
+        lib._lm_batch_declared = True
+
+
+def _set_batch(self, max_batch: int) -> None:
+    """Size the per-sequence state for up to `max_batch` (<= 32) sequences decoded side by side."""
+    _declare_batch(self.ctx.lib)
+    self.ctx.check(self.ctx.lib.mia_lm_set_batch(self.h, int(max_batch)))
+
+
+def _generate_batch(self, prompts, uniforms, temperature=0.6, top_p=0.8, rep_penalty=1.3, rep_window=REPETITION_CONTEXT_SIZE,
+                    max_new_tokens=MAX_TOKEN_COUNT, stop_ids=(END_TOKEN,)) -> list[list[int]]:
+    """generate() for several prompts at once (sentence-level batching): uniforms [n_seq, max_new_tokens]; sequence b's ids equal
+    generate(prompts[b], uniforms[b]).  Call set_batch(n) first."""
+    u = np.ascontiguousarray(uniforms, np.float32)
+    n_seq = len(prompts)
+    if u.ndim != 2 or u.shape[0] != n_seq or u.shape[1] < max_new_tokens:
+        raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, "uniforms must be [n_seq, >= max_new_tokens]")
+    u = np.ascontiguousarray(u[:, :max_new_tokens])
+    offs = np.zeros(n_seq + 1, np.int32)
+    np.cumsum([len(p) for p in prompts], out=offs[1:])
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(p, np.int32) for p in prompts]))
+    sp = _Sampler(temperature, top_p, rep_penalty, rep_window, max_new_tokens, len(stop_ids), (C.c_int32 * 4)(*(list(stop_ids) + [0] * (4 - len(stop_ids)))), 0)
+    out = np.zeros((n_seq, max_new_tokens), np.int32)
+    n = np.zeros(n_seq, np.int32)
+    _declare_batch(self.ctx.lib)
+    self.ctx.check(self.ctx.lib.mia_lm_generate_batch(self.h, flat.ctypes.data, offs.ctypes.data, n_seq, C.byref(sp), u.ctypes.data, out.ctypes.data, n.ctypes.data))
+    return [out[b, :n[b]].tolist() for b in range(n_seq)]
+
+
+CausalLM.set_batch = _set_batch
+CausalLM.generate_batch = _generate_batch
+
+
 def _generate_ras(self, prompt_embeds, uniforms, min_len, max_len, eos, top_p=0.8, top_k=25, win=10, tau=0.1) -> list[int]:
     """mia_lm_generate_ras: embedding-row prompt -> RAS-sampled ids (stops at `eos` once min_len ids are out, or at max_len)."""
     lib = self.ctx.lib

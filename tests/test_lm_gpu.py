@@ -123,6 +123,34 @@ def test_generate_matches_oracle(ctx, cfg_name):
     model.close()
 
 
+@pytest.mark.parametrize("cfg_name", ["llama-micro128", "qwen-micro"])
+def test_generate_batch_equals_single_sequence_runs(ctx, cfg_name):
+    """Sentence-level batching: n prompts of different lengths decoded side by side (rows of the same skinny GEMMs, own K/V cache,
+    repetition window, uniforms and stop state each) give, sequence by sequence, exactly the ids of n separate generate() calls."""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    cfg = S.LM_CONFIGS[cfg_name]
+    w = S.lm_weights(cfg, seed=8, round_to="bf16")
+    model = HL.CausalLM.load(ctx, cfg, w, m.BF16)
+    rng = np.random.default_rng(5)
+    prompts = [rng.integers(0, cfg.vocab - 1, n).tolist() for n in (3, 40, 17, 9, 64)]
+    n_new = 40
+    u = rng.random((len(prompts), n_new)).astype(np.float32)
+    stop = int(rng.integers(0, cfg.vocab))                 # some sequences stop early, the others run to max_new_tokens
+    kw = dict(temperature=0.8, top_p=0.9, rep_penalty=1.2, rep_window=16, max_new_tokens=n_new, stop_ids=(stop,))
+    solo = [model.generate(p, u[b], **kw) for b, p in enumerate(prompts)]
+    model.set_batch(8)
+    both = model.generate_batch(prompts, u, **kw)
+    assert both == solo
+    assert model.generate_batch(prompts[:2], u[:2], **kw) == solo[:2]      # a smaller batch on the same state
+    assert model.generate(prompts[1], u[1], **kw) == solo[1]               # the single-sequence entry point still works on row 0
+    with pytest.raises(m.MiaError):
+        model.generate_batch(prompts * 2, np.concatenate([u, u]), **kw)   # 10 sequences > set_batch(8)
+    model.set_batch(1)
+    assert model.generate(prompts[2], u[2], **kw) == solo[2]
+    model.close()
+
+
 def test_parse_output_host_logic():
     from mlx_swift_audio_amd import lm as HL
     off = HL.CODE_OFFSET

@@ -51,7 +51,23 @@ snac.decode(codes, noise)
 t1 = time.perf_counter()
 pcm = snac.decode(codes, noise)
 ds = time.perf_counter() - t1
-print(json.dumps({"model": name, "prompt_tokens": n_prompt, "generated_tokens": len(gen), "seconds": round(dt, 4),
+# sentence-level batching: argv[4] sequences side by side (same prompt length, own uniforms); weights are read once per step for all
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+batch_res = None
+if batch > 1:
+    model.set_batch(batch)
+    prompts = [rng.integers(0, min(128000, cfg.vocab), n_prompt).tolist() for _ in range(batch)]
+    ub = rng.random((batch, n_new)).astype(np.float32)
+    model.generate_batch(prompts, ub, max_new_tokens=16, stop_ids=(cfg.vocab - 1,))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = model.generate_batch(prompts, ub, max_new_tokens=n_new, stop_ids=(cfg.vocab - 1,))
+    db = time.perf_counter() - t0
+    ntok = sum(len(o) for o in outs)
+    batch_res = {"sequences": batch, "seconds": round(db, 4), "tokens_per_s": round(ntok / db, 1), "ms_per_step": round(db / n_new * 1e3, 3),
+                 "audio_seconds_per_second_lm_only": round((ntok / 7 * 2048 / 24000.0) / db, 2)}
+    model.set_batch(1)
+print(json.dumps({"batch": batch_res, "model": name, "prompt_tokens": n_prompt, "generated_tokens": len(gen), "seconds": round(dt, 4),
                   "prompt_pass_plus_first_step_ms": round(d_prompt * 1e3, 2),
                   "tokens_per_s": round(steps / dt_dec, 1), "ms_per_token": round(dt_dec / steps * 1e3, 3),
                   "weight_GB_per_token": round(bytes_per_tok / 1e9, 3), "hbm_GBs": round(bytes_per_tok * steps / dt_dec / 1e9, 1),
