@@ -100,17 +100,18 @@ __device__ __forceinline__ void rms_store(const f32x4 (&v)[LM_NV], int nv, int D
 }
 
 // x = E[token[pos]] (or a caller-provided embedding row);  h = RMSNorm(x) * w
-// One workgroup per row.  Step graph (pos0 < 0): row b is SEQUENCE b at its own st[b].pos (tokens / embedding rows / state strided per
-// sequence); batched prompt pass (pos0 >= 0): rows are positions pos0 + blockIdx.x of the one sequence the pointers address.
+// One workgroup per row.  Step graph (rowmap == nullptr): row b is SEQUENCE b at its own st[b].pos (tokens / embedding rows / state strided
+// per sequence); batched prompt pass: row r is position rowmap[r].y of sequence rowmap[r].x -- rows of several prompts share a pass.
 template <typename T>
 __global__ __launch_bounds__(256) void lm_embed_norm(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ emb, const uint16_t* __restrict__ gen_emb,
                                                      const float* __restrict__ embeds, const float* __restrict__ w,
-                                                     float* __restrict__ x, uint16_t* __restrict__ h, const LmState* __restrict__ st, int D, float eps, int pos0,
-                                                     int max_ctx) {
+                                                     float* __restrict__ x, uint16_t* __restrict__ h, const LmState* __restrict__ st, int D, float eps,
+                                                     const int2* __restrict__ rowmap, int max_ctx) {
   __shared__ float sh[4];
   const int tid = threadIdx.x, nv = D >> 2;
-  if (pos0 < 0) { st += blockIdx.x; tokens += (int64_t)blockIdx.x * max_ctx; embeds += (int64_t)blockIdx.x * max_ctx * D; }
-  const int pos = pos0 < 0 ? st->pos : pos0 + (int)blockIdx.x;
+  const int seq = rowmap ? rowmap[blockIdx.x].x : (int)blockIdx.x;         // prompt pass: row -> (sequence, position)
+  st += seq; tokens += (int64_t)seq * max_ctx; embeds += (int64_t)seq * max_ctx * D;
+  const int pos = rowmap ? rowmap[blockIdx.x].y : st->pos;
   x += (int64_t)blockIdx.x * D; h += (int64_t)blockIdx.x * D;
   const bool from_rows = pos < st->n_embeds;               // prompt given as embedding rows
   const int tok = from_rows ? 0 : tokens[pos];
@@ -170,10 +171,11 @@ __global__ __launch_bounds__(256) void lm_reduce_norm(const float* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void lm_rope_cache(const float* __restrict__ part, int S, const float* __restrict__ bias, const float* __restrict__ inv_freq,
                                                      uint16_t* __restrict__ qout, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
-                                                     const LmState* __restrict__ st, int Hq, int Hkv, int dh, int max_ctx, int pos0) {
+                                                     const int2* __restrict__ rowmap, int Hq, int Hkv, int dh, int max_ctx, int64_t seq_stride) {
   const int Nq = Hq * dh, Nk = Hkv * dh, N = Nq + 2 * Nk;
   const int half = dh >> 1;
-  const int pos = (pos0 < 0 ? st->pos : pos0) + (int)blockIdx.y;
+  const int pos = rowmap[blockIdx.y].y;
+  kc += (int64_t)rowmap[blockIdx.y].x * seq_stride; vc += (int64_t)rowmap[blockIdx.y].x * seq_stride;
   part += (int64_t)blockIdx.y * N; qout += (int64_t)blockIdx.y * Nq;      // prompt pass: S == 1, one GEMM output row per position
   const int n_pairs = (Hq + Hkv) * half;
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -217,9 +219,10 @@ template <typename T, int DH, bool FUSED>
 __global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __restrict__ q, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
                                                     uint16_t* __restrict__ out, const LmState* __restrict__ st, int Hq, int Hkv, int max_ctx, float scale, int pos0,
                                                     const float* __restrict__ part, int S, const float* __restrict__ bias, const float* __restrict__ inv_freq,
-                                                    int B, int64_t seq_stride) {
+                                                    int B, int64_t seq_stride, const int2* __restrict__ rowmap) {
   extern __shared__ float sc[];            // [max_ctx] scores, then red[ATT_NW][DH] + red2[2 * ATT_NW] (+ FUSED: q, k, v rows [3][DH])
-  if (FUSED) { st += blockIdx.y; kc += (int64_t)blockIdx.y * seq_stride; vc += (int64_t)blockIdx.y * seq_stride; }   // row = sequence
+  const int seq = FUSED ? (int)blockIdx.y : rowmap[blockIdx.y].x;          // FUSED: row = sequence; prompt pass: row -> (sequence, position)
+  st += seq; kc += (int64_t)seq * seq_stride; vc += (int64_t)seq * seq_stride;
   constexpr int LPK = DH / 8;              // lanes per key
   constexpr int KPW = 64 / LPK;            // keys per wave instruction
   float* red = sc + max_ctx;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void lm_attention(const uint16_t* __re
   float* vn = kn + DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, kvh = h / (Hq / Hkv);
-  const int nk = FUSED ? st->pos + 1 : pos0 + (int)blockIdx.y + 1;
+  const int nk = (FUSED ? st->pos : rowmap[blockIdx.y].y) + 1;
   const int nkc = FUSED ? nk - 1 : nk;     // keys read from the cache
   q += (int64_t)blockIdx.y * Hq * DH; out += (int64_t)blockIdx.y * Hq * DH;
   const int c = lane % LPK, g = lane / LPK;
@@ -858,7 +861,7 @@ struct LmLoader {
 int pick_split(int K, int want) { for (int s = want; s > 1; --s) if (K % (32 * s) == 0) return s; return 1; }
 
 // one launch site for the eight (dtype, head_dim, fused) instances
-int lm_launch_attention(mia_lm* m, bool fused, int rows, const void* q, uint16_t* kc, uint16_t* vc, void* att, int pos0, const float* part, int S, const float* bias) {
+int lm_launch_attention(mia_lm* m, bool fused, int rows, const void* q, uint16_t* kc, uint16_t* vc, void* att, const int2* rowmap, const float* part, int S, const float* bias) {
   // fused: rows = sequences (row b uses state b and the b-th cache of the layer); otherwise rows = positions of one sequence
   const int64_t seq_stride = (int64_t)m->cfg.n_kv_heads * m->cfg.max_ctx * m->cfg.head_dim;
   const mia_lm_config& c = m->cfg;
@@ -867,7 +870,7 @@ int lm_launch_attention(mia_lm* m, bool fused, int rows, const void* q, uint16_t
   const size_t lds = (size_t)(c.max_ctx + ATT_NW * dh + 2 * ATT_NW + 3 * dh) * 4;
   const float scale = 1.0f / sqrtf((float)dh);
   const dim3 grid(c.n_heads, rows), block(64 * ATT_NW);
-#define ATT_GO(TT, DD, FF) hipLaunchKernelGGL((lm_attention<TT, DD, FF>), grid, block, lds, s, (const uint16_t*)q, kc, vc, (uint16_t*)att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, pos0, part, S, bias, m->inv_freq, rows, seq_stride)
+#define ATT_GO(TT, DD, FF) hipLaunchKernelGGL((lm_attention<TT, DD, FF>), grid, block, lds, s, (const uint16_t*)q, kc, vc, (uint16_t*)att, m->state, c.n_heads, c.n_kv_heads, c.max_ctx, scale, 0, part, S, bias, m->inv_freq, rows, seq_stride, rowmap)
   const bool f16 = m->dtype == MIA_F16;
   if (dh == 128) { if (fused) { if (f16) ATT_GO(F16, 128, true); else ATT_GO(BF16, 128, true); } else { if (f16) ATT_GO(F16, 128, false); else ATT_GO(BF16, 128, false); } }
   else           { if (fused) { if (f16) ATT_GO(F16, 64, true); else ATT_GO(BF16, 64, true); } else { if (f16) ATT_GO(F16, 64, false); else ATT_GO(BF16, 64, false); } }
@@ -886,14 +889,14 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
     return skinny_gemm_launch(a, mode, m->dtype, s);
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
-  LAUNCH_T(lm_embed_norm, dim3(nb), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps, -1, c.max_ctx);
+  LAUNCH_T(lm_embed_norm, dim3(nb), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps, (const int2*)nullptr, c.max_ctx);
   const size_t layer_stride = (size_t)m->B_cap * c.n_kv_heads * c.max_ctx * dh;
   for (int l = 0; l < c.n_layers; ++l) {
     const LmLayer& L = m->layers[l];
     uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * layer_stride;
     uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * layer_stride;
     if (skinny(m->h, D, L.wqkv, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL)) return -1;
-    lm_launch_attention(m, true, nb, nullptr, kc, vc, m->att, -1, m->qkv_part, m->S_qkv, L.bqkv);      // RoPE + cache row + attention
+    lm_launch_attention(m, true, nb, nullptr, kc, vc, m->att, nullptr, m->qkv_part, m->S_qkv, L.bqkv);      // RoPE + cache row + attention
     if (skinny(m->att, Nq, L.wo, nullptr, m->partial, 0, D, Nq, m->S_o, SK_PARTIAL)) return -1;
     LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_o, L.post_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
     if (skinny(m->h, D, L.wgu, nullptr, m->act, c.inter, 2 * c.inter, D, 1, SK_SWIGLU)) return -1;
@@ -926,17 +929,19 @@ bool lm_prefill_supported(const mia_lm* m) {
   return !off && c.hidden % 64 == 0 && (c.n_heads * c.head_dim) % 64 == 0 && c.inter % 64 == 0;
 }
 
-int lm_prefill(mia_lm* m, int pos0, int P, int seq = 0) {
+// rows: (sequence, position) pairs, every sequence's positions ascending; after the pass set_pos[b] (if >= 0) becomes state b's position
+int lm_prefill_rows(mia_lm* m, const std::vector<int2>& rows, const std::vector<int>& set_pos) {
   mia_ctx* ctx = m->ctx;
   hipStream_t s = ctx->stream;
   const mia_lm_config& c = m->cfg;
   const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh, Nqkv = Nq + 2 * Nk, I = c.inter;
   const bool f16 = m->dtype == MIA_F16;
   const size_t b_x = align_up((size_t)PF_ROWS * D * 4, 256), b_h = align_up((size_t)PF_ROWS * D * 2, 256), b_qkv = align_up((size_t)PF_ROWS * Nqkv * 4, 256),
-               b_q = align_up((size_t)PF_ROWS * Nq * 2, 256), b_gu = align_up((size_t)PF_ROWS * 2 * I * 4, 256), b_act = align_up((size_t)PF_ROWS * I * 2, 256);
+               b_q = align_up((size_t)PF_ROWS * Nq * 2, 256), b_gu = align_up((size_t)PF_ROWS * 2 * I * 4, 256), b_act = align_up((size_t)PF_ROWS * I * 2, 256),
+               b_map = align_up((size_t)PF_ROWS * sizeof(int2), 256);
   if (!m->pf_buf) {
     void* p = nullptr;
-    if (hipMalloc(&p, b_x + b_h + b_qkv + 2 * b_q + b_gu + b_act) != hipSuccess) return mia_fail(ctx, MIA_ERR_OUT_OF_MEMORY, "lm: prompt-pass buffers");
+    if (hipMalloc(&p, b_x + b_h + b_qkv + 2 * b_q + b_gu + b_act + b_map) != hipSuccess) return mia_fail(ctx, MIA_ERR_OUT_OF_MEMORY, "lm: prompt-pass buffers");
     m->allocs.push_back(p); m->pf_buf = (char*)p;
   }
   char* b = m->pf_buf;
@@ -946,7 +951,8 @@ int lm_prefill(mia_lm* m, int pos0, int P, int seq = 0) {
   uint16_t* q = (uint16_t*)b; b += b_q;
   uint16_t* att = (uint16_t*)b; b += b_q;
   float* gu = (float*)b; b += b_gu;
-  uint16_t* act = (uint16_t*)b;
+  uint16_t* act = (uint16_t*)b; b += b_act;
+  int2* rowmap = (int2*)b;
   auto gemm = [&](const void* A, int K, const void* W, const float* bias, float* C, int N, int M, const float* R) {
     GemmArgs g;
     g.A = A; g.lda = K; g.W = W; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K; g.out_f32 = 1;
@@ -955,19 +961,24 @@ int lm_prefill(mia_lm* m, int pos0, int P, int seq = 0) {
     return mia_gemm_launch(g, m->dtype, s);
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
+  const int P = (int)rows.size();
+  const int64_t seq_stride = (int64_t)c.n_kv_heads * c.max_ctx * dh;
+  const size_t layer_stride = (size_t)m->B_cap * seq_stride;
   for (int r0 = 0; r0 < P; r0 += PF_ROWS) {
-    const int M = std::min(PF_ROWS, P - r0), p0 = pos0 + r0;
-    LAUNCH_T(lm_embed_norm, dim3(M), dim3(256), 0, m->tokens + (size_t)seq * c.max_ctx, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed,
-             m->embeds + (size_t)seq * c.max_ctx * D, m->layers[0].in_norm, x, h, m->state + seq, D, c.rms_eps, p0, c.max_ctx);
+    const int M = std::min(PF_ROWS, P - r0);
+    // (pageable source: the copy is staged before the call returns, and the stream orders it behind the previous chunk's kernels)
+    MIA_HIP(ctx, hipMemcpyAsync(rowmap, rows.data() + r0, (size_t)M * sizeof(int2), hipMemcpyHostToDevice, s));
+    LAUNCH_T(lm_embed_norm, dim3(M), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, x, h,
+             m->state, D, c.rms_eps, (const int2*)rowmap, c.max_ctx);
     for (int l = 0; l < c.n_layers; ++l) {
       const LmLayer& L = m->layers[l];
-      uint16_t* kc = (uint16_t*)m->k_cache + ((size_t)l * m->B_cap + seq) * c.n_kv_heads * c.max_ctx * dh;
-      uint16_t* vc = (uint16_t*)m->v_cache + ((size_t)l * m->B_cap + seq) * c.n_kv_heads * c.max_ctx * dh;
+      uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * layer_stride;
+      uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * layer_stride;
       if (gemm(h, D, L.wqkv, nullptr, qkv, Nqkv, M, nullptr)) return MIA_ERR_DEVICE;
       const int n_el = (c.n_heads + c.n_kv_heads) * (dh / 2) + Nk;
-      LAUNCH_T(lm_rope_cache, dim3((n_el + 255) / 256, M), dim3(256), 0, qkv, 1, L.bqkv, m->inv_freq, q, kc, vc, m->state + seq, c.n_heads, c.n_kv_heads, dh, c.max_ctx, p0);
+      LAUNCH_T(lm_rope_cache, dim3((n_el + 255) / 256, M), dim3(256), 0, qkv, 1, L.bqkv, m->inv_freq, q, kc, vc, (const int2*)rowmap, c.n_heads, c.n_kv_heads, dh, c.max_ctx, seq_stride);
       if (l + 1 == c.n_layers) break;            // past its K/V rows the last layer feeds only the head, which the prompt pass skips
-      lm_launch_attention(m, false, M, q, kc, vc, att, p0, nullptr, 0, nullptr);
+      lm_launch_attention(m, false, M, q, kc, vc, att, rowmap, nullptr, 0, nullptr);
       if (gemm(att, Nq, L.wo, nullptr, x, D, M, x)) return MIA_ERR_DEVICE;                // x += att . Wo^T
       LAUNCH_T(lm_reduce_norm, dim3(M), dim3(256), 0, (const float*)nullptr, 0, L.post_norm, x, h, D, c.rms_eps, 1);
       if (gemm(h, D, L.wgu, nullptr, gu, 2 * I, M, nullptr)) return MIA_ERR_DEVICE;
@@ -978,9 +989,19 @@ int lm_prefill(mia_lm* m, int pos0, int P, int seq = 0) {
     }
   }
 #undef LAUNCH_T
-  hipLaunchKernelGGL(lm_set_pos, dim3(1), dim3(1), 0, s, m->state + seq, pos0 + P);
+  for (size_t sq = 0; sq < set_pos.size(); ++sq)
+    if (set_pos[sq] >= 0) hipLaunchKernelGGL(lm_set_pos, dim3(1), dim3(1), 0, s, m->state + sq, set_pos[sq]);
   if (hipGetLastError() != hipSuccess) return mia_fail(ctx, MIA_ERR_DEVICE, "lm: prompt-pass launch failed");
   return MIA_OK;
+}
+
+// positions [pos0, pos0 + P) of one sequence
+int lm_prefill(mia_lm* m, int pos0, int P, int seq = 0) {
+  std::vector<int2> rows(P);
+  for (int i = 0; i < P; ++i) rows[i] = make_int2(seq, pos0 + i);
+  std::vector<int> set_pos(seq + 1, -1);
+  set_pos[seq] = pos0 + P;
+  return lm_prefill_rows(m, rows, set_pos);
 }
 
 int lm_graph(mia_lm* m, int mode, const mia_lm_sampler& sp, const RasParams* ras = nullptr, int nb = 1) {
@@ -1257,10 +1278,16 @@ extern "C" int mia_lm_generate_batch(mia_lm* m, const int32_t* prompts, const in
   // not available every sequence walks its prompt in the step graph (the sampler idles until its own prompt is consumed)
   const bool pre = lm_prefill_supported(m);
   int first_steps = 0;
-  for (int b = 0; b < n_seq; ++b) {
-    const int np_ = st[b].n_prompt;
-    if (pre && np_ - 1 >= 1) { if (const int rc = lm_prefill(m, 0, np_ - 1, b)) return rc; }
-    else first_steps = std::max(first_steps, np_ - 1);
+  if (pre) {                                             // the rows of all prompts share the GEMMs of one prompt pass
+    std::vector<int2> rows;
+    std::vector<int> set_pos(n_seq, -1);
+    for (int b = 0; b < n_seq; ++b) {
+      for (int i = 0; i + 1 < st[b].n_prompt; ++i) rows.push_back(make_int2(b, i));
+      if (st[b].n_prompt > 1) set_pos[b] = st[b].n_prompt - 1;
+    }
+    if (!rows.empty()) { if (const int rc = lm_prefill_rows(m, rows, set_pos)) return rc; }
+  } else {
+    for (int b = 0; b < n_seq; ++b) first_steps = std::max(first_steps, st[b].n_prompt - 1);
   }
   const int total = first_steps + mn;
   for (int step = 0; step < total; ++step) {
