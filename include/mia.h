@@ -316,6 +316,12 @@ typedef struct { float top_p; int32_t top_k; int32_t win; float tau; int32_t eos
  * the caller.  uniforms: the stream of explicit draws (one per categorical; rejected EOS trials consume more).  Host pointers. */
 int mia_lm_generate_ras(mia_lm* lm, const float* prompt_embeds, int n_prompt, const mia_ras_params* rp, const float* uniforms,
                         int n_uniforms, int32_t* out_tokens, int32_t* n_out);
+/* mia_lm_generate_ras for n_seq utterances side by side (after mia_lm_set_batch): prompt_embeds = the rows of all prompts back to back
+ * [prompt_offsets[n_seq]][hidden]; rp [n_seq] (top_p, top_k, win, tau, eos must agree; min_len / max_len are per utterance); uniforms
+ * [n_seq][n_uniforms]; out_tokens [n_seq][out_stride], out_stride >= max(max_len) + 1; n_out [n_seq].  Utterance b's ids equal
+ * mia_lm_generate_ras(prompt b, rp[b], uniforms row b).  Host pointers. */
+int mia_lm_generate_ras_batch(mia_lm* lm, const float* prompt_embeds, const int32_t* prompt_offsets, int n_seq, const mia_ras_params* rp,
+                              const float* uniforms, int n_uniforms, int32_t* out_tokens, int out_stride, int32_t* n_out);
 /* One sampleNextToken call on caller-provided logits (host pointers). */
 int mia_sample_top_p(mia_ctx* ctx, const float* logits, int V, const int32_t* history, int n_hist, float rep_penalty,
                      float temperature, float top_p, float uniform, int32_t* out);

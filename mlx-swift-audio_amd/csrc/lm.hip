@@ -20,7 +20,7 @@
 #include "decode.h"
 #include "gemm.h"
 
-struct LmState { int pos; int n_hist; int finished; int n_gen; int n_embeds; int n_out; int u_cursor; int n_prompt; };
+struct LmState { int pos; int n_hist; int finished; int n_gen; int n_embeds; int n_out; int u_cursor; int n_prompt; int min_len; int max_len; };   // min/max_len: RAS loop, per sequence
 
 struct RasParams { float top_p; int top_k; int win; float tau; int eos; int min_len; int max_len; int n_uniforms; };
 
@@ -680,6 +680,9 @@ __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ 
   __shared__ int topi[32];
   __shared__ int s_tok[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // one workgroup per sequence; the text-length-dependent bounds of the loop live in the sequence's state
+  st += blockIdx.x; logits += (int64_t)blockIdx.x * V; tokens += (int64_t)blockIdx.x * max_ctx; out_tokens += (int64_t)blockIdx.x * max_ctx;
+  uniforms += (int64_t)blockIdx.x * max_ctx;
   const int pos = st->pos, n_prompt = st->n_embeds;
   const int cur_len = pos + 1;
   if (cur_len < n_prompt || st->finished) { __syncthreads(); if (tid == 0 && !st->finished) st->pos = pos + 1; return; }
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ 
     }
     pick = s_tok[0];
     ++trials;
-    const bool ignore_eos = step_i < rp.min_len;
+    const bool ignore_eos = step_i < st->min_len;
     if (!(ignore_eos && pick == rp.eos) || trials > 100) break;   // the Swift throws after 100 rejected trials; we keep the EOS
     __syncthreads();
   }
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ 
     else {
       if (cur_len < max_ctx) tokens[cur_len] = pick;     // embedding input of the next step (speech_embedding[pick])
       if (pick < rp.eos) { out_tokens[st->n_out] = pick; st->n_out += 1; }   // ids above EOS (fill tokens) are fed back, not emitted
-      if (step_i + 1 >= rp.max_len || cur_len + 1 >= max_ctx) st->finished = 1;
+      if (step_i + 1 >= st->max_len || cur_len + 1 >= max_ctx) st->finished = 1;
       st->pos = pos + 1;
     }
   }
@@ -906,7 +909,7 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
 #undef LAUNCH_T
   const int HV = m->head_vocab > 0 ? m->head_vocab : c.vocab;
   if (skinny(m->h, D, m->lm_head, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32)) return -1;
-  if (ras) hipLaunchKernelGGL(lm_sample_ras, dim3(1), dim3(1024), 0, s, m->logits, HV, m->tokens, m->out_tokens, m->uniforms, m->state, *ras, c.max_ctx);
+  if (ras) hipLaunchKernelGGL(lm_sample_ras, dim3(nb), dim3(1024), 0, s, m->logits, HV, m->tokens, m->out_tokens, m->uniforms, m->state, *ras, c.max_ctx);
   else if (sampling) { if (lm_sample_launch(s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx, nb)) return -1; }
   else hipLaunchKernelGGL(lm_advance, dim3(nb), dim3(1), 0, s, m->state);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -1050,7 +1053,7 @@ int lm_alloc_state(mia_lm* m, int B) {
   m->partial = (float*)dev((size_t)8 * B * D * 4); m->logits = (float*)dev((size_t)B * std::max(c.vocab, m->head_vocab) * 4);
   m->tokens = (int32_t*)dev((size_t)B * c.max_ctx * 4); m->hist = (int32_t*)dev((size_t)B * 64 * 4); m->uniforms = (float*)dev((size_t)B * c.max_ctx * 4);
   m->state = (LmState*)dev(sizeof(LmState) * B);
-  m->embeds = (float*)dev((size_t)c.max_ctx * D * 4); m->out_tokens = (int32_t*)dev((size_t)c.max_ctx * 4);     // RAS path: one sequence
+  m->embeds = (float*)dev((size_t)B * c.max_ctx * D * 4); m->out_tokens = (int32_t*)dev((size_t)B * c.max_ctx * 4);
   if (!ok) return -1;
   (void)hipMemset(m->k_cache, 0, kv); (void)hipMemset(m->v_cache, 0, kv); (void)hipMemset(m->state, 0, sizeof(LmState) * B);
   m->B_cap = B;
@@ -1354,13 +1357,13 @@ extern "C" int mia_lm_generate_ras(mia_lm* m, const float* prompt_embeds, int n_
   MIA_CHECK_ARG(ctx, rp->top_k > 0 && rp->top_k <= 32 && rp->win >= 0 && rp->win <= 64 && rp->eos >= 0 && rp->eos < m->head_vocab, "lm_generate_ras: bad sampler parameters");
   MIA_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  LmState st{}; st.n_embeds = n_prompt;
+  LmState st{}; st.n_embeds = n_prompt; st.min_len = rp->min_len; st.max_len = rp->max_len;
   MIA_HIP(ctx, hipMemcpyAsync(m->state, &st, sizeof(st), hipMemcpyHostToDevice, s));
   MIA_HIP(ctx, hipMemcpyAsync(m->embeds, prompt_embeds, (size_t)n_prompt * m->cfg.hidden * 4, hipMemcpyHostToDevice, s));
   const int nu = std::min(n_uniforms, m->cfg.max_ctx);
   MIA_HIP(ctx, hipMemcpyAsync(m->uniforms, uniforms, (size_t)nu * 4, hipMemcpyHostToDevice, s));
   MIA_HIP(ctx, hipStreamSynchronize(s));
-  RasParams r{rp->top_p, rp->top_k, rp->win, rp->tau, rp->eos, rp->min_len, rp->max_len, nu};
+  RasParams r{rp->top_p, rp->top_k, rp->win, rp->tau, rp->eos, 0, 0, nu};      // (the length bounds travel in the state: one graph serves every text length)
   mia_lm_sampler none{};
   const int gr = lm_graph(m, 2, none, &r);
   if (gr < 0) return gr;
@@ -1383,6 +1386,78 @@ extern "C" int mia_lm_generate_ras(mia_lm* m, const float* prompt_embeds, int n_
   MIA_HIP(ctx, hipStreamSynchronize(s));
   *n_out = st.n_out;
   MIA_HIP(ctx, hipMemcpyAsync(out_tokens, m->out_tokens, (size_t)st.n_out * 4, hipMemcpyDeviceToHost, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  return MIA_OK;
+}
+
+// mia_lm_generate_ras for n_seq utterances side by side (see mia_lm_generate_batch).  prompt_embeds: the rows of all prompts back to back
+// [prompt_offsets[n_seq]][hidden]; rp [n_seq]: top_p / top_k / win / tau / eos must agree, min_len / max_len are per utterance;
+// uniforms [n_seq][n_uniforms]; out_tokens [n_seq][out_stride] with out_stride >= max(max_len) + 1; n_out [n_seq].
+extern "C" int mia_lm_generate_ras_batch(mia_lm* m, const float* prompt_embeds, const int32_t* prompt_offsets, int n_seq, const mia_ras_params* rp,
+                                         const float* uniforms, int n_uniforms, int32_t* out_tokens, int out_stride, int32_t* n_out) {
+  if (!m) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = m->ctx;
+  MIA_CHECK_ARG(ctx, prompt_embeds && prompt_offsets && rp && uniforms && n_uniforms > 0 && out_tokens && n_out, "lm_generate_ras_batch: null arguments");
+  MIA_CHECK_ARG(ctx, n_seq >= 1 && n_seq <= m->B_cap, "lm_generate_ras_batch: n_seq %d exceeds the batch set with mia_lm_set_batch (%d)", n_seq, m->B_cap);
+  MIA_CHECK_ARG(ctx, m->gen_embed && m->head_vocab > 0 && m->head_vocab <= 1024 * RAS_NPT, "lm_generate_ras_batch: model has no (or too large a) speech head");
+  const int C = m->cfg.max_ctx, D = m->cfg.hidden;
+  int max_len = 0;
+  for (int b = 0; b < n_seq; ++b) {
+    const int np_ = prompt_offsets[b + 1] - prompt_offsets[b];
+    MIA_CHECK_ARG(ctx, np_ > 0 && rp[b].max_len > 0 && np_ + rp[b].max_len <= C, "lm_generate_ras_batch: utterance %d: prompt + max_len exceeds max_ctx", b);
+    MIA_CHECK_ARG(ctx, rp[b].top_p == rp[0].top_p && rp[b].top_k == rp[0].top_k && rp[b].win == rp[0].win && rp[b].tau == rp[0].tau && rp[b].eos == rp[0].eos,
+                  "lm_generate_ras_batch: top_p / top_k / win / tau / eos must be the same for all utterances");
+    max_len = std::max(max_len, rp[b].max_len);
+  }
+  MIA_CHECK_ARG(ctx, rp[0].top_k > 0 && rp[0].top_k <= 32 && rp[0].top_k <= m->head_vocab && rp[0].win >= 0 && rp[0].win <= 64 && rp[0].eos >= 0 && rp[0].eos < m->head_vocab,
+                "lm_generate_ras_batch: bad sampler parameters");
+  MIA_CHECK_ARG(ctx, out_stride >= max_len + 1, "lm_generate_ras_batch: out_stride must hold max_len + 1 ids");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int nu = std::min(n_uniforms, C);
+  std::vector<LmState> st(n_seq);
+  for (int b = 0; b < n_seq; ++b) {
+    const int np_ = prompt_offsets[b + 1] - prompt_offsets[b];
+    st[b] = LmState{}; st[b].n_embeds = np_; st[b].min_len = rp[b].min_len; st[b].max_len = rp[b].max_len;
+    MIA_HIP(ctx, hipMemcpyAsync(m->embeds + (size_t)b * C * D, prompt_embeds + (size_t)prompt_offsets[b] * D, (size_t)np_ * D * 4, hipMemcpyHostToDevice, s));
+    MIA_HIP(ctx, hipMemcpyAsync(m->uniforms + (size_t)b * C, uniforms + (size_t)b * n_uniforms, (size_t)nu * 4, hipMemcpyHostToDevice, s));
+  }
+  MIA_HIP(ctx, hipMemcpyAsync(m->state, st.data(), sizeof(LmState) * n_seq, hipMemcpyHostToDevice, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  RasParams r{rp[0].top_p, rp[0].top_k, rp[0].win, rp[0].tau, rp[0].eos, 0, 0, nu};
+  mia_lm_sampler none{};
+  const int gr = lm_graph(m, 2, none, &r, n_seq);
+  if (gr < 0) return gr;
+  int first_steps = 0;
+  if (lm_prefill_supported(m)) {
+    std::vector<int2> rows;
+    std::vector<int> set_pos(n_seq, -1);
+    for (int b = 0; b < n_seq; ++b) {
+      for (int i = 0; i + 1 < st[b].n_embeds; ++i) rows.push_back(make_int2(b, i));
+      if (st[b].n_embeds > 1) set_pos[b] = st[b].n_embeds - 1;
+    }
+    if (!rows.empty()) { if (const int rc = lm_prefill_rows(m, rows, set_pos)) return rc; }
+  } else {
+    for (int b = 0; b < n_seq; ++b) first_steps = std::max(first_steps, st[b].n_embeds - 1);
+  }
+  const int total = first_steps + max_len;
+  for (int step = 0; step < total; ++step) {
+    if (gr == 0) MIA_HIP(ctx, hipGraphLaunch(m->graph, s));
+    else if (lm_enqueue_step(m, true, none, -1, &r, n_seq)) return mia_fail(ctx, MIA_ERR_DEVICE, "lm_generate_ras_batch: launch failed");
+    if ((step & 15) == 15) {
+      MIA_HIP(ctx, hipMemcpyAsync(st.data(), m->state, sizeof(LmState) * n_seq, hipMemcpyDeviceToHost, s));
+      MIA_HIP(ctx, hipStreamSynchronize(s));
+      bool all = true;
+      for (int b = 0; b < n_seq; ++b) all = all && st[b].finished;
+      if (all) break;
+    }
+  }
+  MIA_HIP(ctx, hipMemcpyAsync(st.data(), m->state, sizeof(LmState) * n_seq, hipMemcpyDeviceToHost, s));
+  MIA_HIP(ctx, hipStreamSynchronize(s));
+  for (int b = 0; b < n_seq; ++b) {
+    n_out[b] = st[b].n_out;
+    if (st[b].n_out > 0) MIA_HIP(ctx, hipMemcpyAsync(out_tokens + (size_t)b * out_stride, m->out_tokens + (size_t)b * C, (size_t)st[b].n_out * 4, hipMemcpyDeviceToHost, s));
+  }
   MIA_HIP(ctx, hipStreamSynchronize(s));
   return MIA_OK;
 }

@@ -165,6 +165,32 @@ def _generate_ras(self, prompt_embeds, uniforms, min_len, max_len, eos, top_p=0.
 CausalLM.generate_ras = _generate_ras
 
 
+def _generate_ras_batch(self, prompt_embeds, uniforms, min_lens, max_lens, eos, top_p=0.8, top_k=25, win=10, tau=0.1) -> list[list[int]]:
+    """mia_lm_generate_ras_batch: one embedding-row prompt, (min_len, max_len) pair and uniform row per utterance; set_batch(n) first."""
+    lib = self.ctx.lib
+    if not getattr(lib, "_ras_batch_declared", False):
+        lib.mia_lm_generate_ras_batch.restype = C.c_int
+        lib.mia_lm_generate_ras_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_Ras), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        lib._ras_batch_declared = True
+    n_seq = len(prompt_embeds)
+    xs = [np.ascontiguousarray(x, np.float32) for x in prompt_embeds]
+    offs = np.zeros(n_seq + 1, np.int32)
+    np.cumsum([x.shape[0] for x in xs], out=offs[1:])
+    flat = np.ascontiguousarray(np.concatenate(xs, axis=0))
+    rps = (_Ras * n_seq)(*[_Ras(top_p, top_k, win, tau, eos, int(min_lens[b]), int(max_lens[b])) for b in range(n_seq)])
+    u = np.ascontiguousarray(uniforms, np.float32)
+    if u.ndim != 2 or u.shape[0] != n_seq:
+        raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, "uniforms must be [n_seq, n_uniforms]")
+    stride = int(max(max_lens)) + 1
+    out = np.zeros((n_seq, stride), np.int32)
+    n = np.zeros(n_seq, np.int32)
+    self.ctx.check(lib.mia_lm_generate_ras_batch(self.h, flat.ctypes.data, offs.ctypes.data, n_seq, rps, u.ctypes.data, u.shape[1], out.ctypes.data, stride, n.ctypes.data))
+    return [out[b, :n[b]].tolist() for b in range(n_seq)]
+
+
+CausalLM.generate_ras_batch = _generate_ras_batch
+
+
 def sample_next_token(ctx: _lib.Context, logits: np.ndarray, history, uniform: float, temperature=0.6, top_p=0.8, rep_penalty=1.3) -> int:
     """sampleNextToken(logits:history:temperature:topP:repetitionPenalty:) with an explicit uniform for the categorical draw."""
     _declare(ctx.lib)

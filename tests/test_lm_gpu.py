@@ -133,7 +133,7 @@ def test_generate_batch_equals_single_sequence_runs(ctx, cfg_name):
     w = S.lm_weights(cfg, seed=8, round_to="bf16")
     model = HL.CausalLM.load(ctx, cfg, w, m.BF16)
     rng = np.random.default_rng(5)
-    prompts = [rng.integers(0, cfg.vocab - 1, n).tolist() for n in (3, 40, 17, 9, 64)]
+    prompts = [rng.integers(0, cfg.vocab - 1, n).tolist() for n in (3, 40, 1, 17, 9, 64)]      # incl. a one-token prompt (no prompt-pass rows)
     n_new = 40
     u = rng.random((len(prompts), n_new)).astype(np.float32)
     stop = int(rng.integers(0, cfg.vocab))                 # some sequences stop early, the others run to max_new_tokens
@@ -145,7 +145,7 @@ def test_generate_batch_equals_single_sequence_runs(ctx, cfg_name):
     assert model.generate_batch(prompts[:2], u[:2], **kw) == solo[:2]      # a smaller batch on the same state
     assert model.generate(prompts[1], u[1], **kw) == solo[1]               # the single-sequence entry point still works on row 0
     with pytest.raises(m.MiaError):
-        model.generate_batch(prompts * 2, np.concatenate([u, u]), **kw)   # 10 sequences > set_batch(8)
+        model.generate_batch(prompts * 2, np.concatenate([u, u]), **kw)   # 12 sequences > set_batch(8)
     model.set_batch(1)
     assert model.generate(prompts[2], u[2], **kw) == solo[2]
     model.close()
@@ -180,4 +180,27 @@ def test_qwen2lm_ras_inference_matches_oracle(ctx):
     assert all(0 <= t < S_TOK for t in got) and len(got) >= int(len(text) * 2.0) - 1
     k = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
     assert k >= 6, (got, ref)                         # streams may fork at an f16-moved CDF / top-k boundary, never early
+    model.close()
+
+
+def test_ras_batch_equals_single_utterance_runs(ctx):
+    """CosyVoice2 utterance-level batching: embedding-row prompts of different lengths, per-utterance (min_len, max_len) and uniform
+    streams (EOS rejections consume extra draws per utterance) -- ids identical to separate generate_ras calls."""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    cfg = S.LM_CONFIGS["qwen-micro"]
+    S_TOK = 200
+    w = S.lm_weights(cfg, seed=5, round_to="f16")
+    w.update(S.qwen2lm_extra_weights(cfg, S_TOK, seed=5, round_to="f16"))
+    model = HL.CausalLM.load(ctx, cfg, w, m.F16)
+    rng = np.random.default_rng(11)
+    lens = (15, 4, 33, 9)
+    xs = [rng.standard_normal((n, cfg.hidden)).astype(np.float32) for n in lens]
+    mins, maxs = [12, 3, 20, 8], [60, 25, 90, 40]
+    u = rng.random((len(xs), 600)).astype(np.float32)
+    solo = [model.generate_ras(xs[b], u[b], mins[b], maxs[b], S_TOK) for b in range(len(xs))]
+    assert all(mins[b] - 1 <= len(solo[b]) <= maxs[b] for b in range(len(xs)))
+    model.set_batch(4)
+    assert model.generate_ras_batch(xs, u, mins, maxs, S_TOK) == solo
+    assert model.generate_ras(xs[2], u[2], mins[2], maxs[2], S_TOK) == solo[2]
     model.close()
