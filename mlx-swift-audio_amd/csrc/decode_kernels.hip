@@ -31,6 +31,14 @@ template <typename T>
 __device__ __forceinline__ void row_layernorm_store(const f32x4 (&v)[ROW_NV], int nv, int D, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, uint16_t* __restrict__ hrow, float* sh) {
   const int tid = threadIdx.x;
+  // gamma / beta do not depend on the statistics: fetch them first, so their L2 round trip overlaps the two block reductions
+  f32x4 gm[ROW_NV], bt[ROW_NV];
+#pragma unroll
+  for (int i = 0; i < ROW_NV; ++i) {
+    const bool in = tid + 256 * i < nv;
+    gm[i] = in ? *reinterpret_cast<const f32x4*>(gamma + 4 * (tid + 256 * i)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    bt[i] = in ? *reinterpret_cast<const f32x4*>(beta + 4 * (tid + 256 * i)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < ROW_NV; ++i) if (tid + 256 * i < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -47,11 +55,9 @@ __device__ __forceinline__ void row_layernorm_store(const f32x4 (&v)[ROW_NV], in
   for (int i = 0; i < ROW_NV; ++i) {
     const int c = tid + 256 * i;
     if (c >= nv) continue;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
-    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 4 * c);
     float o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bt[j];
+    for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * gm[i][j] + bt[i][j];
     *reinterpret_cast<u32x2*>(hrow + 4 * c) = (u32x2){pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
   }
 }

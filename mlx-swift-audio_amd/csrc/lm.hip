@@ -86,6 +86,10 @@ __device__ __forceinline__ float blk256_sum(float v, float* sh) {
 template <typename T>
 __device__ __forceinline__ void rms_store(const f32x4 (&v)[LM_NV], int nv, int D, float eps, const float* __restrict__ w, uint16_t* __restrict__ h, float* sh) {
   const int tid = threadIdx.x;
+  // the norm weights do not depend on the reduction: fetch them before it, so their L2 round trip overlaps the two barriers
+  f32x4 g[LM_NV];
+#pragma unroll
+  for (int i = 0; i < LM_NV; ++i) g[i] = tid + 256 * i < nv ? *reinterpret_cast<const f32x4*>(w + 4 * (tid + 256 * i)) : (f32x4){0.f, 0.f, 0.f, 0.f};
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < LM_NV; ++i) if (tid + 256 * i < nv) q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
@@ -94,8 +98,7 @@ __device__ __forceinline__ void rms_store(const f32x4 (&v)[LM_NV], int nv, int D
   for (int i = 0; i < LM_NV; ++i) {
     const int c = tid + 256 * i;
     if (c >= nv) continue;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(w + 4 * c);
-    *reinterpret_cast<u32x2*>(h + 4 * c) = (u32x2){pack2<T>(v[i][0] * rstd * g[0], v[i][1] * rstd * g[1]), pack2<T>(v[i][2] * rstd * g[2], v[i][3] * rstd * g[3])};
+    *reinterpret_cast<u32x2*>(h + 4 * c) = (u32x2){pack2<T>(v[i][0] * rstd * g[i][0], v[i][1] * rstd * g[i][1]), pack2<T>(v[i][2] * rstd * g[i][2], v[i][3] * rstd * g[i][3])};
   }
 }
 
