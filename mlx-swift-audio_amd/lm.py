@@ -268,3 +268,22 @@ class OrpheusTTS:
         if noise is not None:
             nz = np.ascontiguousarray(noise[:self.snac.noise_len(4 * n)], np.float32)
         return gen, self.snac.decode(codes, nz)
+
+    def generate_chunks(self, input_ids_list, uniforms, noises=None, temperature=0.6, top_p=0.8, max_new_tokens=MAX_TOKEN_COUNT):
+        """The sentence loop of OrpheusTTS.generate (OrpheusTTS.swift:179-191) with the sentences' LM loops side by side
+        (CausalLM.generate_batch; call lm.set_batch(n) first): one (ids, pcm) pair per sentence, identical to generate_chunk per
+        sentence with the same uniforms / noise.  uniforms [n, max_new_tokens]; noises: one array per sentence or None."""
+        gens = self.lm.generate_batch(input_ids_list, uniforms, temperature=temperature, top_p=top_p, rep_penalty=1.3,
+                                      rep_window=REPETITION_CONTEXT_SIZE, max_new_tokens=max_new_tokens, stop_ids=(END_TOKEN,))
+        out = []
+        lim = self.snac.cfg.codebook_size
+        for b, gen in enumerate(gens):
+            codes = parse_output(list(input_ids_list[b]) + gen)
+            if not codes[0]:
+                out.append((gen, np.zeros(0, np.float32)))
+                continue
+            n = len(codes[0])
+            codes = [[min(max(c, 0), lim - 1) for c in lv] for lv in codes]
+            nz = None if noises is None or noises[b] is None else np.ascontiguousarray(noises[b][:self.snac.noise_len(4 * n)], np.float32)
+            out.append((gen, self.snac.decode(codes, nz)))
+        return out

@@ -204,3 +204,27 @@ def test_ras_batch_equals_single_utterance_runs(ctx):
     assert model.generate_ras_batch(xs, u, mins, maxs, S_TOK) == solo
     assert model.generate_ras(xs[2], u[2], mins[2], maxs[2], S_TOK) == solo[2]
     model.close()
+
+
+def test_orpheus_sentence_loop_batched_equals_sequential(ctx):
+    """OrpheusTTS mirror: generate_chunks (sentences side by side) returns, per sentence, what generate_chunk returns.  (With a
+    3 000-id micro vocabulary no id falls in Orpheus' audio-code range, so the SNAC leg yields empty audio on both sides; the SNAC
+    decoder itself is covered by test_codec_gpu.py and parse_output by test_parse_output_host_logic.)"""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import codec as HC, lm as HL
+    cfg = S.LM_CONFIGS["llama-micro"]
+    w = S.lm_weights(cfg, seed=9, round_to="bf16")
+    model = HL.CausalLM.load(ctx, cfg, w, m.BF16)
+    scfg = S.SNAC_CONFIGS["snac_micro"]
+    snac = HC.SNACDecoder.load(ctx, scfg, S.snac_weights(scfg, 1))
+    tts = HL.OrpheusTTS(model, snac)
+    rng = np.random.default_rng(2)
+    sents = [rng.integers(0, cfg.vocab, n).tolist() for n in (12, 30, 5)]
+    u = rng.random((3, 24)).astype(np.float32)
+    seq = [tts.generate_chunk(sents[b], u[b], max_new_tokens=24) for b in range(3)]
+    model.set_batch(3)
+    par = tts.generate_chunks(sents, u, max_new_tokens=24)
+    assert [g for g, _ in par] == [g for g, _ in seq]
+    assert all(np.array_equal(a, b) for (_, a), (_, b) in zip(par, seq))
+    snac.close()
+    model.close()
