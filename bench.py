@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--max-new-tokens", type=int, default=0, help="cap generated tokens per clip (0 = full 448 budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="skip the SNAC/DAC decode samples/s side measurement")
-    ap.add_argument("--cpu-tokens", type=int, default=24, help="greedy steps actually run by the CPU baseline")
+    ap.add_argument("--cpu-tokens", type=int, default=200, help="greedy steps actually run by the CPU baseline (the rest of the 445-step budget is extrapolated linearly)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--replicas", type=int, default=2,
                     help="model replicas on separate HIP streams; passes are dealt round-robin so the encoder of one batch overlaps the decoder of another (1 = strictly serial passes)")
