@@ -179,6 +179,29 @@ def codec_bench(ctx, torch):
                                         "total_frames": Tm, "euler_steps": fcfg.n_timesteps,
                                         "realtime_factor": round(n_new / 50.0 / (ms * 1e-3), 1)}
     fm.close()
+    # ---- S3TokenizerV2 (CosyVoice2 prompt path): 10 s of 128-bin mel @ 100 Hz -> 250 speech tokens
+    from mlx_swift_audio_amd import s3tok as HS
+    scfg = S.S3_CONFIGS["s3_v2"]
+    tk = HS.S3Tokenizer.load(ctx, scfg, S.s3_weights(scfg, 0))
+    Ts = 1000
+    smel = torch.randn(1, scfg.n_mels, Ts, device="cuda").contiguous()
+    stoks = torch.zeros(1, Ts // 4 + 8, dtype=torch.int32, device="cuda")
+    slen = np.asarray([Ts], np.int32)
+    sn = np.zeros(1, np.int32)
+
+    def run_s3():
+        ctx.check(ctx.lib.mia_s3tok_encode(tk.h, smel.data_ptr(), slen.ctypes.data, 1, Ts, stoks.data_ptr(), stoks.shape[1], sn.ctypes.data, 1))
+
+    run_s3()
+    e0.record()
+    for _ in range(reps):
+        run_s3()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    res["s3tokenizer_v2_encode"] = {"tokens_per_s": round(int(sn[0]) / (ms * 1e-3), 0), "ms": round(ms, 3), "mel_frames": Ts, "tokens": int(sn[0]),
+                                    "realtime_factor": round(Ts / 100.0 / (ms * 1e-3), 1)}
+    tk.close()
     return res
 
 
