@@ -65,6 +65,43 @@ def cpu_baseline(dims_name: str, seed: int, n_threads: int, max_new_tokens: int)
                        f"{n_tok} greedy steps {t3 - t2:.2f}s scaled to {full_tokens} steps")}
 
 
+def lm_bench(ctx, torch, name: str, batch: int):
+    """BASELINE.json configs[2] ("Orpheus-3B TTS: Llama-3 backbone autoregress + SNAC codec decode"), the LM half: random-init bf16
+    weights, 64-token prompts, 210 sampled tokens (30 SNAC frames); one sequence, then `batch` sentences side by side.  Host-inclusive
+    wall clock (the loop lives behind the C ABI; only the early-exit poll touches the host)."""
+    from mlx_swift_audio_amd import lm as HL
+    from mlx_swift_audio_amd import synthetic as S
+    import mlx_swift_audio_amd as m
+    cfg = S.LM_CONFIGS[name]
+    model = HL.CausalLM.load(ctx, cfg, S.lm_weights(cfg, seed=0, dtype=np.float16), m.BF16)
+    rng = np.random.default_rng(0)
+    n_new, n_prompt = 210, 64
+    stop = (cfg.vocab - 1,)
+    prompt = rng.integers(0, min(128000, cfg.vocab), n_prompt).tolist()
+    u = rng.random(n_new).astype(np.float32)
+    model.generate(prompt, u, max_new_tokens=16, stop_ids=stop)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gen = model.generate(prompt, u, max_new_tokens=n_new, stop_ids=stop)
+    d1 = time.perf_counter() - t0
+    params = cfg.vocab * cfg.hidden + cfg.n_layers * ((cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim * cfg.hidden + cfg.hidden * cfg.n_heads * cfg.head_dim + 3 * cfg.inter * cfg.hidden)
+    res = {"model": name, "prompt_tokens": n_prompt, "generated_tokens": len(gen), "tokens_per_s": round(len(gen) / d1, 1), "ms_per_token_incl_prompt": round(d1 / len(gen) * 1e3, 3),
+           "weight_GB_per_token": round(2.0 * params / 1e9, 3), "hbm_GBs": round(2.0 * params * len(gen) / d1 / 1e9, 1)}
+    if batch > 1:
+        model.set_batch(batch)
+        prompts = [rng.integers(0, min(128000, cfg.vocab), n_prompt).tolist() for _ in range(batch)]
+        ub = rng.random((batch, n_new)).astype(np.float32)
+        model.generate_batch(prompts, ub, max_new_tokens=16, stop_ids=stop)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = model.generate_batch(prompts, ub, max_new_tokens=n_new, stop_ids=stop)
+        db = time.perf_counter() - t0
+        ntok = sum(len(o) for o in outs)
+        res["batched"] = {"sequences": batch, "tokens_per_s": round(ntok / db, 1), "audio_seconds_per_second": round(ntok / 7 * 2048 / 24000.0 / db, 1)}
+    model.close()
+    return res
+
+
 def codec_bench(ctx, torch):
     """Second half of BASELINE.json's metric ("codec samples/s"): SNAC 24 kHz decode of one Orpheus chunk (1200 tokens ->
     171 frames -> 350 208 samples) and DAC speech decode of 10 s (750 code steps), random-init weights,
@@ -218,6 +255,8 @@ def main():
     ap.add_argument("--no-codec", action="store_true", help="skip the SNAC/DAC decode samples/s side measurement")
     ap.add_argument("--cpu-tokens", type=int, default=200, help="greedy steps actually run by the CPU baseline (the rest of the 445-step budget is extrapolated linearly)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--lm", default="", help="also time an LM decode loop and add it as `lm` (e.g. orpheus-3b: ~40 s of extra set-up; off by default)")
+    ap.add_argument("--lm-batch", type=int, default=32, help="sentences side by side in the batched part of --lm")
     ap.add_argument("--replicas", type=int, default=2,
                     help="model replicas on separate HIP streams; passes are dealt round-robin so the encoder of one batch overlaps the decoder of another (1 = strictly serial passes)")
     args = ap.parse_args()
@@ -413,6 +452,8 @@ def main():
     if rank == 0 and not args.no_codec:
         torch.cuda.set_stream(reps[0].stream)     # the codec leg times library work with torch events: same stream as the context
         out["codec"] = codec_bench(ctx, torch)
+    if rank == 0 and args.lm:
+        out["lm"] = lm_bench(ctx, torch, args.lm, args.lm_batch)
     if rank == 0 and not args.no_cpu_baseline:
         try:
             ncpu = min(16, len(os.sched_getaffinity(0)))   # the GPU box's CPU share for one GPU is 16 cores
