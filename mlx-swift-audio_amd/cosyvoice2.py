@@ -69,3 +69,37 @@ class CosyVoice2Model:
         mel = self.tokens_to_mel(np.asarray(tokens, np.int32), cond.prompt_speech_token, cond.prompt_mel, cond.speaker_embedding, z_fn(T), n_timesteps)
         noise = noise_fn(mel.shape[1] * self.hifigan.up) if noise_fn is not None else None
         return self.mel_to_audio(mel, noise), tokens
+
+    # ---- the other three modes (CosyVoice2Model.swift:253-397): the same three stages, different prompts ----------------------------------
+    def _tokens_to_audio(self, tokens, cond, z_fn, noise_fn, n_timesteps):
+        if not len(tokens):
+            raise ValueError("No tokens generated")
+        T = 2 * (len(tokens) + len(cond.prompt_speech_token))
+        mel = self.tokens_to_mel(np.asarray(tokens, np.int32), cond.prompt_speech_token, cond.prompt_mel, cond.speaker_embedding, z_fn(T), n_timesteps)
+        noise = noise_fn(mel.shape[1] * self.hifigan.up) if noise_fn is not None else None
+        return self.mel_to_audio(mel, noise), list(tokens)
+
+    def synthesize_cross_lingual(self, text, cond: CosyVoice2Conditionals, uniforms, z_fn, noise_fn=None, sampling: int = 25, n_timesteps: int = 10,
+                                 max_token_text_ratio: float = 20.0, min_token_text_ratio: float = 2.0):
+        """synthesizeCrossLingual (:253-310): the LM sees neither the prompt's text nor its speech tokens; the flow and the vocoder
+        still condition on the reference clip."""
+        tokens = self.generate_tokens(text, (), (), uniforms, sampling, max_token_text_ratio, min_token_text_ratio)
+        return self._tokens_to_audio(tokens, cond, z_fn, noise_fn, n_timesteps)
+
+    def synthesize_instruct(self, text, instruct_text, cond: CosyVoice2Conditionals, uniforms, z_fn, noise_fn=None, sampling: int = 25,
+                            n_timesteps: int = 10, max_token_text_ratio: float = 20.0, min_token_text_ratio: float = 2.0):
+        """synthesizeInstruct (:312-369): the instruction's ids take the prompt-text slot, no prompt speech tokens in the LM."""
+        tokens = self.generate_tokens(text, instruct_text, (), uniforms, sampling, max_token_text_ratio, min_token_text_ratio)
+        return self._tokens_to_audio(tokens, cond, z_fn, noise_fn, n_timesteps)
+
+    def synthesize_vc(self, source_speech_token, cond: CosyVoice2Conditionals, z_fn, noise_fn=None, n_timesteps: int = 10):
+        """synthesizeVC (:371-397): voice conversion -- the source clip's S3 tokens go straight to the flow with the target's conditionals."""
+        return self._tokens_to_audio(list(np.asarray(source_speech_token).reshape(-1)), cond, z_fn, noise_fn, n_timesteps)[0]
+
+    def tokenize_speech(self, wav_24k: np.ndarray) -> np.ndarray:
+        """The source side of voice conversion (prepareSourceAudioForVC, CosyVoice2TTS.swift:624-653): 24 kHz clip -> S3 tokens."""
+        from . import audio as A
+        wav16 = A.resample_audio(self.ctx, np.ascontiguousarray(wav_24k, np.float32)[:30 * 24000], 24000, 16000)
+        mel128 = A.s3_log_mel_spectrogram(self.ctx, wav16, 128)
+        tk, nt = self.s3.quantize(mel128[None], np.asarray([mel128.shape[1]], np.int32))
+        return np.asarray(tk[0][:int(nt[0])], np.int32)

@@ -73,6 +73,18 @@ def test_zero_shot_pipeline(ctx):
     again, tokens2 = model.synthesize(text, cond, u, z_fn, noise_fn)
     assert tokens2 == tokens
     np.testing.assert_array_equal(again, audio)
+    # ---- the other three modes are the same stages with different prompts (CosyVoice2Model.swift:253-397)
+    xa, xt = model.synthesize_cross_lingual(text, cond, u, z_fn, noise_fn)
+    assert xt == llm.inference(text, [], [], u) and xa.shape == (2 * len(xt) * 480,) and np.isfinite(xa).all()
+    ia, it = model.synthesize_instruct(text, [3, 4], cond, u, z_fn, noise_fn)
+    assert it == llm.inference(text, [3, 4], [], u) and ia.shape == (2 * len(it) * 480,)
+    src = model.tokenize_speech(OL.synth_clip(9, 36000))                      # 1.5 s source clip -> 37-38 tokens
+    assert 36 <= src.shape[0] <= 38 and (0 <= src).all() and (src < S_TOK).all()
+    va = model.synthesize_vc(src, cond, z_fn, noise_fn)
+    want_vc, _ = OF.inference(fw, fcfg, src, cond.prompt_speech_token, cond.prompt_mel, cond.speaker_embedding, draws["z"])
+    got_vc = model.tokens_to_mel(src, cond.prompt_speech_token, cond.prompt_mel, cond.speaker_embedding, draws["z"])
+    np.testing.assert_allclose(got_vc, want_vc, atol=2e-3, rtol=2e-3)
+    assert va.shape == (2 * src.shape[0] * 480,) and np.abs(va).max() <= 0.99 + 1e-7
     for h in (flow, hift, s3, spk_enc):
         h.close()
     llm.lm.close()
