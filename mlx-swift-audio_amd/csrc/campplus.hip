@@ -149,24 +149,34 @@ __global__ __launch_bounds__(256) void cam_bn_relu(const float* __restrict__ x, 
 
 // CAMLayer's mask (CAMPPlus.swift:470-503): context = mean over all frames + mean over the frame's 100-frame segment (a short last
 // segment still divides by 100: the reference zero-pads before averaging); gate = sigmoid(W2 relu(W1 context + b1) + b2).
-// The context is constant inside a segment, so the two 1x1 layers run once per segment: one workgroup per segment.
-__global__ __launch_bounds__(128) void cam_gate(const float* __restrict__ h, int T, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gate) {
+// The context is constant inside a segment, so the two 1x1 layers run once per segment: one workgroup per segment (8 row groups
+// share the frame loop).
+__global__ __launch_bounds__(1024) void cam_gate(const float* __restrict__ h, int T, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                 const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gate) {
+  __shared__ float ptot[8][128];
+  __shared__ float pseg[8][128];
   __shared__ float ctx[128];
   __shared__ float hid[64];
-  const int seg = blockIdx.x, c = threadIdx.x;
+  const int seg = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;        // 8 row groups x 128 channels
   float tot = 0.f, sg = 0.f;
   const int lo = seg * SEG_LEN, hi = min(T, lo + SEG_LEN);
-  for (int t = 0; t < T; ++t) { const float v = h[(int64_t)t * 128 + c]; tot += v; if (t >= lo && t < hi) sg += v; }
-  ctx[c] = tot / (float)T + sg / (float)SEG_LEN;
+  for (int t = grp; t < T; t += 8) { const float v = h[(int64_t)t * 128 + c]; tot += v; if (t >= lo && t < hi) sg += v; }
+  ptot[grp][c] = tot; pseg[grp][c] = sg;
   __syncthreads();
-  if (c < 64) {
+  if (threadIdx.x < 128) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { a += ptot[g][c]; b += pseg[g][c]; }
+    ctx[c] = a / (float)T + b / (float)SEG_LEN;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
     float a = b1[c];
     for (int k = 0; k < 128; ++k) a = fmaf(w1[c * 128 + k], ctx[k], a);
     hid[c] = fmaxf(a, 0.f);
   }
   __syncthreads();
-  if (c < 32) {
+  if (threadIdx.x < 32) {
     float a = b2[c];
     for (int k = 0; k < 64; ++k) a = fmaf(w2[c * 64 + k], hid[k], a);
     gate[seg * 32 + c] = 1.0f / (1.0f + expf(-a));
@@ -480,7 +490,7 @@ int run_encoder(mia_campplus* m, const float* fb, int T, float* ws, float* emb) 
       hipLaunchKernelGGL(cam_bn_relu, nblk((int64_t)Tt * d.cin), dim3(256), 0, s, cat[b], ld[b], tmp, (int64_t)d.cin, Tt, d.cin, d.bn1.scale, d.bn1.shift);
       if (int rc = run_lin(ctx, d.lin1, tmp, d.cin, Tt, hb, 128, Tt, 1, 1, 0, 6)) return rc;
       if (int rc = run_lin(ctx, d.local, hb, 128, Tt, yb, 32, Tt, 1, d.dil, d.dil, 0)) return rc;
-      hipLaunchKernelGGL(cam_gate, dim3(nseg), dim3(128), 0, s, hb, Tt, d.w1, d.b1, d.w2, d.b2, gate);
+      hipLaunchKernelGGL(cam_gate, dim3(nseg), dim3(1024), 0, s, hb, Tt, d.w1, d.b1, d.w2, d.b2, gate);
       hipLaunchKernelGGL(cam_apply, nblk((int64_t)Tt * 32), dim3(256), 0, s, yb, gate, cat[b] + d.cin, ld[b], Tt);
     }
     ch += 32 * (int)m->layers[b].size();
