@@ -703,9 +703,75 @@ __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ 
 #pragma unroll
   for (int u = 0; u < RAS_NPT; ++u) if (tid + 1024 * u < V) tot += __expf(x[u] - mx);
   tot = blk1024_sum(tot, sh);
-  // top-k by iterated workgroup argmax (k <= 32): (value, index) with lowest index on ties; a taken entry is struck out in its
-  // owner's register.  One barrier per round: the wave winners go to a double-buffered LDS row and every thread merges them.
+  // top-k (k <= 32), ordered by (value desc, index asc).  Fast path: a 3-level radix select (11 | 11 | 10 bits of the order-preserving
+  // key, integer LDS atomics, one wave walks the bins) finds the k-th largest key, the <= 32 survivors are gathered and rank-sorted:
+  // 8 barriers instead of one per rank (the iterated argmax below measured 2.1 us per round, 52 of the kernel's 60 us).  It is kept as
+  // the fallback for the one case the select cannot order by itself: more logits equal to the threshold than slots left for them.
   const int K = rp.top_k < 32 ? rp.top_k : 32;
+  __shared__ unsigned rh[3][2048];
+  __shared__ int r_sel[4];                               // bin, count above it, count in it, gather cursor
+  __shared__ float candv[32];
+  __shared__ int candi[32];
+  for (int i = tid; i < 3 * 2048; i += 1024) (&rh[0][0])[i] = 0u;
+  if (tid == 0) r_sel[3] = 0;
+  unsigned key[RAS_NPT];
+#pragma unroll
+  for (int u = 0; u < RAS_NPT; ++u) {
+    const unsigned bits = __float_as_uint(x[u]);
+    key[u] = tid + 1024 * u < V ? ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u)) : 0u;    // 0 sorts below every float
+  }
+  __syncthreads();
+  bool fast = true;
+  {
+    unsigned prefix = 0u, mask = 0u;
+    int need = K, c_thr = 0;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+#pragma unroll
+    for (int lvl = 0; lvl < 3; ++lvl) {
+      const int shf = shifts[lvl], nb = 1 << widths[lvl];
+#pragma unroll
+      for (int u = 0; u < RAS_NPT; ++u)
+        if (key[u] != 0u && (key[u] & mask) == prefix) atomicAdd(&rh[lvl][(key[u] >> shf) & (unsigned)(nb - 1)], 1u);
+      if (tid == 0) r_sel[0] = -1;
+      __syncthreads();
+      if (wave == 0) {                                   // lane l owns the bins nb-1 - per*l ... nb-per*(l+1), walked downwards
+        const int per = nb >> 6;
+        int mine = 0;
+        for (int j = 0; j < per; ++j) mine += (int)rh[lvl][nb - 1 - (per * lane + j)];
+        const int incl = wave_incl_scan(mine, lane), excl = incl - mine;
+        if (excl < need && incl >= need) {
+          int cum = excl;
+          for (int j = 0; j < per; ++j) {
+            const int bin = nb - 1 - (per * lane + j), cnt = (int)rh[lvl][bin];
+            if (cum + cnt >= need) { r_sel[0] = bin; r_sel[1] = cum; r_sel[2] = cnt; break; }
+            cum += cnt;
+          }
+        }
+      }
+      __syncthreads();
+      if (r_sel[0] < 0) { fast = false; break; }        // fewer than k candidates (cannot happen for k <= V finite logits)
+      prefix |= (unsigned)r_sel[0] << shf;
+      mask |= (unsigned)(nb - 1) << shf;
+      need -= r_sel[1];
+      c_thr = r_sel[2];
+      __syncthreads();
+    }
+    if (fast && c_thr > need) fast = false;              // ties at the threshold would have to be split by index: ordered path
+    if (fast) {
+#pragma unroll
+      for (int u = 0; u < RAS_NPT; ++u)
+        if (key[u] != 0u && key[u] >= prefix) { const int slot = atomicAdd(&r_sel[3], 1); if (slot < 32) { candv[slot] = x[u]; candi[slot] = tid + 1024 * u; } }
+      __syncthreads();
+      if (tid < K) {
+        const float v = candv[tid]; const int ix = candi[tid];
+        int rank = 0;
+        for (int j = 0; j < K; ++j) rank += (candv[j] > v || (candv[j] == v && candi[j] < ix)) ? 1 : 0;
+        topv[rank] = __expf(v - mx) / tot; topi[rank] = ix;
+      }
+      __syncthreads();
+    }
+  }
+  if (!fast) {
   for (int r = 0; r < K; ++r) {
     float bv = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
@@ -728,6 +794,7 @@ __global__ __launch_bounds__(1024) void lm_sample_ras(const float* __restrict__ 
     }
   }
   __syncthreads();
+  }
   // per-wave partial sums of the full softmax in index order (for the fallback draw)
   const int per_wave = (V + 15) / 16;
   const int w_lo = wave * per_wave, w_hi = min(V, w_lo + per_wave);

@@ -228,3 +228,40 @@ def test_orpheus_sentence_loop_batched_equals_sequential(ctx):
     assert all(np.array_equal(a, b) for (_, a), (_, b) in zip(par, seq))
     snac.close()
     model.close()
+
+
+@pytest.mark.parametrize("n_tied", [5, 40])
+def test_ras_top_k_with_exact_ties(ctx, n_tied):
+    """The RAS sampler's top-k is a radix select with an ordered fallback when logits EQUAL to the k-th largest outnumber the slots left
+    for them.  A zero llm_decoder weight makes every step's logits equal its bias, so exact ties can be planted: 5 tied values inside
+    the top 25 (select path), 40 tied values straddling rank 25 (fallback path: the 15 lowest ids among them are kept).  Token streams
+    must equal the oracle's stable-sort definition."""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    cfg = S.LM_CONFIGS["qwen-micro"]
+    S_TOK = 200
+    w = S.lm_weights(cfg, seed=5, round_to="f16")
+    w.update(S.qwen2lm_extra_weights(cfg, S_TOK, seed=5, round_to="f16"))
+    rng = np.random.default_rng(n_tied)
+    bias = (rng.standard_normal(S_TOK + 3) * 0.5 - 4.0).astype(np.float32)
+    ids = rng.permutation(S_TOK)                        # eos (= S_TOK) and the fill ids above it stay unlikely
+    bias[ids[:10]] = np.linspace(3.0, 2.1, 10, dtype=np.float32)
+    bias[ids[10:10 + n_tied]] = np.float32(1.5)
+    w["llm_decoder.weight"] = np.zeros_like(w["llm_decoder.weight"])
+    w["llm_decoder.bias"] = bias
+    model = HL.CausalLM.load(ctx, cfg, w, m.F16)
+    x = rng.standard_normal((6, cfg.hidden)).astype(np.float32)
+    u = rng.random(400).astype(np.float32)
+    n = 60
+    got = model.generate_ras(x, u, 0, n, S_TOK)
+    logp = bias.astype(np.float64) - np.log(np.exp(bias.astype(np.float64)).sum())
+    draws = iter(list(u) + [u[-1]] * 1000)
+    want = []
+    for _ in range(n):
+        t = OL.ras_sampling(logp, want, draws)
+        if t == S_TOK:
+            break
+        if t < S_TOK:
+            want.append(t)
+    assert got == want
+    model.close()
