@@ -189,6 +189,9 @@ void mia_whisper_free(mia_whisper* w);
  * context (= another HIP stream) of the same device -- for decoding different batches concurrently (the reference has one model per
  * actor; this is the serving-side counterpart).  Free every clone before the handle it was cloned from. */
 mia_whisper* mia_whisper_clone(mia_whisper* src, mia_ctx* ctx);
+/* Test hook: force the encoder GEMM tile variant (0 / 1: 128^2 register / LDS-DMA staged, 2: 256^2 two-buffer, 3: automatic
+ * (default), 4: 256^2 8-phase).  Results are identical up to fp32 summation order; anything else is MIA_ERR_INVALID_ARGUMENT. */
+int mia_whisper_set_gemm_variant(mia_whisper* w, int variant);
 
 /* Replaces model.encode(mel) (WhisperDecoding.swift:98 -> AudioEncoder.swift:43-68) for a batch of 30 s windows and
  * primes the decoder's cross-attention K/V (MultiHeadAttention.swift:49-59).

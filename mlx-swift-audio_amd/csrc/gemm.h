@@ -24,7 +24,7 @@ struct GemmArgs {
   int out_f32 = 0;
   int epi = MIA_EPI_STD;
   int T = 0, H = 0, Tpad = 0;   // special epilogues: m = b*T + t, n = h*64 + d
-  int variant = 3;              // 0: 128^2 register-staged, 1: 128^2 LDS-DMA staged, 2: 256^2 LDS-DMA staged, 3: auto (2 when it fills the chip, else 1)
+  int variant = 3;              // 0: 128^2 register-staged, 1: 128^2 LDS-DMA staged, 2: 256^2 two-buffer LDS-DMA, 4: 256^2 8-phase LDS-DMA ring, 3: auto (4 when it fills the chip, else 1)
 };
 
 // returns nullptr when the arguments satisfy the kernel's shape/alignment assumptions, else a message

@@ -12,6 +12,7 @@
 // issued with W as the "A" operand, so each lane's 4 accumulator registers run along N (contiguous in C):
 // the epilogue emits 8-byte (16-bit C) or 16-byte (fp32 C) stores.
 // Workgroup ids are remapped so that the blocks sharing an XCD (and its private L2) walk neighbouring tiles.
+#include <mutex>
 #include <type_traits>
 
 #include "gemm.h"
@@ -341,13 +342,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256(GemmArgs g) {
       }
     }
   };
-  const bool diag_no_reload = g.variant == 5;          // timing-only diagnostic build path (tools/gemm_bench.py): results are wrong
   auto main_loop = [&](auto swap_tag) {
     int cur = 0;
     stage_dma(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk && !diag_no_reload) stage_dma(cur ^ 1, (kt + 1) * BK);
+      if (kt + 1 < nk) stage_dma(cur ^ 1, (kt + 1) * BK);
       compute(cur, swap_tag);
       __syncthreads();
       cur ^= 1;
@@ -392,6 +392,265 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_256(GemmArgs g) {
   }
 }
 
+
+// ---- 256x256x64 tile, 8 phases per two K-tiles (cdna_hip_programming.md "The 256^2 8-phase template", rebuilt here).
+// 512 threads = 2(M) x 4(N) waves, each wave 128x64 (32 accumulator tiles = 128 registers).  Per K-tile four phases of
+// 16 MFMAs (one 64x32 quadrant x K=64); every phase is  {ds_reads | one LDS-DMA item | counted vmcnt} s_barrier
+// {lgkmcnt(0) | 16 MFMA} s_barrier.  The two wave groups (waves 0-3 = row half 0, waves 4-7 = row half 1; one of each per SIMD)
+// run ONE barrier apart, so while one group's wave owns the SIMD's matrix pipe the other one reads LDS and issues DMA.
+//
+// LDS (128 KB) = 2 K-tile buffers x 4 items of 16 KB (128 rows x 128 B, 16-B chunk index XOR (row & 7)):
+//   AX = rows {0..63, 128..191} of the A tile (the first 64 rows of either group's 128), AY = the other 64 of each,
+//   B0 / B1 = W rows 0..127 / 128..255.  Items are issued in the fixed order [AX B0 B1 AY] of tile 0, 1, 2, ... -- one per
+//   phase, six ahead of the consumer -- so a counted `s_waitcnt vmcnt(6)` (three items stay in flight) retires exactly the
+//   item the NEXT phase reads.  Rules kept (MI355X_MICROARCH.md item 7, guide "Read a staged buffer one phase AFTER the
+//   wait that retires it"): wait in phase i -> first read in phase i+1; a region is re-staged >= 2 phases after the phase
+//   whose lgkmcnt(0) retired its last read (the groups are one barrier apart).
+//   reads : phi1 fa0 (8) + fw[nt 0,1] (4) | phi2 fw[nt 2,3] (4) + fa1[mt 4,5] (4) | phi3 fa1[mt 6,7] (4) | phi4 none
+//   issue : phi1 B1(t+1) | phi2 AY(t+1) | phi3 AX(t+2) | phi4 B0(t+2)         waits: phi1 -> AY(t), phi4 -> AX,B0,B1(t+1)
+constexpr int ITEM_BYTES = 128 * 128;      // 16 KB
+constexpr int KBUF_BYTES = 4 * ITEM_BYTES; // one K-tile: [B0][B1][AX][AY]
+constexpr int OFF_B0 = 0, OFF_B1 = ITEM_BYTES, OFF_AX = 2 * ITEM_BYTES, OFF_AY = 3 * ITEM_BYTES;
+
+#define MIA_BAR()                                 \
+  do {                                            \
+    asm volatile("" ::: "memory");                \
+    __builtin_amdgcn_s_barrier();                 \
+    asm volatile("" ::: "memory");                \
+  } while (0)
+
+__device__ __forceinline__ void wait_items(int allowed) {   // wave-uniform: leave `allowed` items (2 LDS-DMA each) in flight
+  if (allowed >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (allowed == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (allowed == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename T, bool OUT_F32, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [2 K-tile buffers][B0|B1|AX|AY] = 128 KB (the only LDS object)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (g.N + BN2 - 1) / BN2;
+  const int tiles_m = (g.M + BM2 - 1) / BM2;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  int tm, tn;
+  tile_of(bid, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM2, n0 = tn * BN2;
+  const int bz = blockIdx.z;
+  const char* __restrict__ Ab = reinterpret_cast<const char*>(reinterpret_cast<const uint16_t*>(g.A) + (int64_t)bz * g.strideA);
+  const char* __restrict__ Wb = reinterpret_cast<const char*>(g.W);
+
+  // ---- LDS-DMA sources: this wave fills LDS rows 16*wave + 8*i + (lane>>3), i = 0, 1, of every item; lane&7 is the 16-B position
+  // in the 128-B row, which holds logical chunk (lane&7) ^ (row&7): the swizzle sits on the SOURCE address, the LDS image is lane-linear.
+  uint32_t ax_off[2], ay_off[2], b0_off[2], b1_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 16 * wave + 8 * i + (lane >> 3);
+    const int chk = (lane & 7) ^ (row & 7);
+    const int arow = (row >> 6) * 128 + (row & 63);
+    int ax = m0 + arow, ay = m0 + arow + 64, w0 = n0 + row, w1 = n0 + 128 + row;
+    ax = ax < g.M ? ax : g.M - 1; ay = ay < g.M ? ay : g.M - 1;     // clamp: tail rows are computed but never stored
+    w0 = w0 < g.N ? w0 : g.N - 1; w1 = w1 < g.N ? w1 : g.N - 1;
+    ax_off[i] = (uint32_t)(((int64_t)ax * g.lda + chk * 8) * 2);
+    ay_off[i] = (uint32_t)(((int64_t)ay * g.lda + chk * 8) * 2);
+    b0_off[i] = (uint32_t)(((int64_t)w0 * g.K + chk * 8) * 2);
+    b1_off[i] = (uint32_t)(((int64_t)w1 * g.K + chk * 8) * 2);
+  }
+  const int nk = g.K / BK;
+  const int n_items = 4 * nk;
+  char* const lds_wave = lds + (16 * wave) * 128;
+  // item j = 4*t + {0: AX, 1: B0, 2: B1, 3: AY} of K-tile t
+  auto stage_item = [&](int j) {
+    if (j >= n_items) return;
+    const int t = j >> 2, which = j & 3;
+    char* dst = lds_wave + (t & 1) * KBUF_BYTES;
+    const int kb = t * (BK * 2);
+    if (which == 0) {
+      glds16(Ab + ax_off[0] + kb, dst + OFF_AX); glds16(Ab + ax_off[1] + kb, dst + OFF_AX + 1024);
+    } else if (which == 1) {
+      glds16(Wb + b0_off[0] + kb, dst + OFF_B0); glds16(Wb + b0_off[1] + kb, dst + OFF_B0 + 1024);
+    } else if (which == 2) {
+      glds16(Wb + b1_off[0] + kb, dst + OFF_B1); glds16(Wb + b1_off[1] + kb, dst + OFF_B1 + 1024);
+    } else {
+      glds16(Ab + ay_off[0] + kb, dst + OFF_AY); glds16(Ab + ay_off[1] + kb, dst + OFF_AY + 1024);
+    }
+  };
+
+  // ---- fragment read offsets: row = base + (lane & 15), logical chunk = kk*4 + (lane >> 4)
+  const int f_row = lane & 15, f_chk = lane >> 4;
+  int a_rd[2], b_rd[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int sw = ((kk * 4 + f_chk) ^ (f_row & 7)) << 4;
+    a_rd[kk] = (wr * 64 + f_row) * 128 + sw;                                   // + OFF_AX / OFF_AY + t*2048
+    b_rd[kk] = (wc >> 1) * ITEM_BYTES + ((wc & 1) * 64 + f_row) * 128 + sw;    // + t*2048
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bool v_tile = EPI == MIA_EPI_QKV_VT && n0 >= 2 * g.H * 64;   // V tiles: operands swapped, rows <- m (see gemm_nt_kernel_256)
+
+  auto main_loop = [&](auto swap_tag) {
+    constexpr bool SWAP = decltype(swap_tag)::value;
+    s16x8 fa0[2][4], fa1[2][4], fw[2][4];
+    auto mma16 = [&](const s16x8 (&fa)[2][4], int mbase, int nbase) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mbase + mt][nbase + nt] = SWAP ? T::mfma16(fa[kk][mt], fw[kk][nbase + nt], acc[mbase + mt][nbase + nt])
+                                               : T::mfma16(fw[kk][nbase + nt], fa[kk][mt], acc[mbase + mt][nbase + nt]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto ktile = [&](int kt, auto par_tag) {
+      constexpr int P = decltype(par_tag)::value;
+      const char* buf = lds + P * KBUF_BYTES;
+      const int j0 = 4 * kt;
+      // ---------------- phi1
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fw[kk][t] = *reinterpret_cast<const s16x8*>(buf + OFF_B0 + b_rd[kk] + t * 2048);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa0[kk][t] = *reinterpret_cast<const s16x8*>(buf + OFF_AX + a_rd[kk] + t * 2048);
+      }
+      stage_item(j0 + 6);
+      wait_items(min(j0 + 7, n_items) - (j0 + 4));          // AY(kt) landed (read in phi2)
+      MIA_BAR();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(fa0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      MIA_BAR();
+      // ---------------- phi2
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int t = 2; t < 4; ++t) fw[kk][t] = *reinterpret_cast<const s16x8*>(buf + OFF_B0 + b_rd[kk] + t * 2048);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa1[kk][t] = *reinterpret_cast<const s16x8*>(buf + OFF_AY + a_rd[kk] + t * 2048);
+      }
+      stage_item(j0 + 7);
+      MIA_BAR();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(fa0, 0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      MIA_BAR();
+      // ---------------- phi3
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int t = 2; t < 4; ++t) fa1[kk][t] = *reinterpret_cast<const s16x8*>(buf + OFF_AY + a_rd[kk] + t * 2048);
+      }
+      stage_item(j0 + 8);
+      MIA_BAR();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(fa1, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      MIA_BAR();
+      // ---------------- phi4
+      stage_item(j0 + 9);
+      if (kt + 1 < nk) wait_items(min(j0 + 10, n_items) - (j0 + 7));   // AX, B0, B1 of tile kt+1 landed (read in the next phi1)
+      MIA_BAR();
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(fa1, 4, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      MIA_BAR();
+    };
+    // ---- prologue: tile 0 whole + AX, B0 of tile 1 (items 0..5); items 0..2 must have landed before the first reads
+#pragma unroll
+    for (int j = 0; j < 6; ++j) stage_item(j);
+    wait_items(min(6, n_items) - 3);
+    MIA_BAR();
+    if (wr == 1) MIA_BAR();          // stagger: the second wave group runs one barrier behind the first
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(kt, std::integral_constant<int, 0>{});
+      if (kt + 1 < nk) ktile(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (wr == 0) MIA_BAR();
+  };
+  if (EPI == MIA_EPI_QKV_VT && v_tile) main_loop(std::true_type{}); else main_loop(std::false_type{});
+
+  if (EPI == MIA_EPI_QKV_VT && v_tile) {
+    const int D2 = 2 * g.H * 64;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = m0 + wr * 128 + mt * 16 + (lane >> 4) * 4;
+      if (m >= g.M) continue;
+      const int b = m / g.T, t = m - b * g.T;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + (lane & 15);
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.f;
+        const f32x4 a = acc[mt][nt];
+        uint16_t* vt = reinterpret_cast<uint16_t*>(g.C2) + ((int64_t)b * g.H * 64 + (n - D2)) * g.Tpad + t;
+        *reinterpret_cast<u32x2*>(vt) = (u32x2){pack2<T>(a[0] + bias, a[1] + bias), pack2<T>(a[2] + bias, a[3] + bias)};
+      }
+    }
+    return;
+  }
+  const int e_m = lane & 15, e_n = (lane >> 4) * 4;
+  const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && (g.R == nullptr || (g.ldr & 3) == 0);
+  f32x4 bias4[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) bias4[nt] = load_bias4(g, n0 + wc * 64 + nt * 16 + e_n);
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = m0 + wr * 128 + mt * 16 + e_m;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wc * 64 + nt * 16 + e_n;
+      if (n >= g.N) continue;
+      epilogue_store<T, OUT_F32, EPI>(g, bz, m, n, acc[mt][nt], bias4[nt], vec_ok);
+    }
+  }
+}
+
+template <typename T>
+int launch_8ph(const GemmArgs& g, hipStream_t s) {
+  const int tiles = ((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
+  dim3 grid(tiles, 1, g.batch > 0 ? g.batch : 1), block(512);
+  const size_t lds_bytes = 2 * KBUF_BYTES;
+#define L8(F32, E)                                                                                                \
+  do {                                                                                                            \
+    static std::once_flag once;                                                                                   \
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_8ph<T, F32, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF_BYTES); }); \
+    hipLaunchKernelGGL((gemm_nt_kernel_8ph<T, F32, E>), grid, block, lds_bytes, s, g);                             \
+  } while (0)
+  if (g.epi == MIA_EPI_STD) { if (g.out_f32) L8(true, MIA_EPI_STD); else L8(false, MIA_EPI_STD); }
+  else if (g.epi == MIA_EPI_QKV_VT) L8(false, MIA_EPI_QKV_VT);
+  else L8(false, MIA_EPI_HEADMAJOR);
+#undef L8
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 template <typename T>
 int launch_256(const GemmArgs& g, hipStream_t s) {
   const int tiles = ((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
@@ -399,8 +658,8 @@ int launch_256(const GemmArgs& g, hipStream_t s) {
   const size_t lds_bytes = 4 * TILE2_BYTES;
 #define L256(F32, E)                                                                                              \
   do {                                                                                                            \
-    static bool attr = false;                                                                                     \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_256<T, F32, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr = true; } \
+    static std::once_flag once;                                                                                   \
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_256<T, F32, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE2_BYTES); }); \
     hipLaunchKernelGGL((gemm_nt_kernel_256<T, F32, E>), grid, block, lds_bytes, s, g);                             \
   } while (0)
   if (g.epi == MIA_EPI_STD) { if (g.out_f32) L256(true, MIA_EPI_STD); else L256(false, MIA_EPI_STD); }
@@ -429,10 +688,14 @@ template <typename T>
 int launch_t(const GemmArgs& g, hipStream_t s) {
   if (g.variant == 0) return launch_ts<T, 0>(g, s);
   if (g.variant == 1) return launch_ts<T, 1>(g, s);
-  if (g.variant == 2 || g.variant == 5) return launch_256<T>(g, s);
+  if (g.variant == 2) return launch_256<T>(g, s);
+  // the 8-phase kernel addresses A and W through 32-bit byte offsets from the (per-batch) base and needs two K-tiles
+  const bool ok8 = g.K >= 2 * BK && (int64_t)g.M * g.lda * 2 < (1ll << 32) && (int64_t)g.N * g.K * 2 < (1ll << 32);
+  if (g.variant == 4) return ok8 ? launch_8ph<T>(g, s) : launch_256<T>(g, s);
   // auto: the 256^2 tile needs enough tiles to fill 256 CUs; small problems keep the 128^2 tile
   const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.batch > 0 ? g.batch : 1);
-  return tiles256 >= 256 ? launch_256<T>(g, s) : launch_ts<T, 1>(g, s);
+  if (tiles256 < 256) return launch_ts<T, 1>(g, s);
+  return ok8 ? launch_8ph<T>(g, s) : launch_256<T>(g, s);
 }
 
 }  // namespace

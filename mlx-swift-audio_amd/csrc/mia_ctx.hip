@@ -115,8 +115,6 @@ extern "C" int mia_profile_enable(mia_ctx* ctx, int on) {
 extern "C" int mia_profile_reset(mia_ctx* ctx) {
   if (!ctx) return MIA_ERR_INVALID_ARGUMENT;
   MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (void* p : ctx->table_allocs) (void)hipFree(p);
-  if (ctx->s3gen_mel) free(ctx->s3gen_mel);
   for (auto& r : ctx->prof) { ctx->ev_pool.push_back(r.start); ctx->ev_pool.push_back(r.stop); }
   ctx->prof.clear();
   return MIA_OK;
@@ -129,8 +127,6 @@ extern "C" int mia_profile_read(mia_ctx* ctx, const char* kernel_class, int64_t*
   MIA_CHECK_ARG(ctx, cls >= 0, "profile_read: unknown kernel class '%s'", kernel_class);
   MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int64_t n = 0; double ms = 0.0, work = 0.0;
-  for (void* p : ctx->table_allocs) (void)hipFree(p);
-  if (ctx->s3gen_mel) free(ctx->s3gen_mel);
   for (auto& r : ctx->prof) {
     if (r.cls != cls) continue;
     float t = 0.f;

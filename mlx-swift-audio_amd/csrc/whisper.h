@@ -62,7 +62,9 @@ struct mia_whisper {
   mia_whisper_dims dims{};
   int dtype = MIA_BF16;
   int kpad_conv1 = 0;
+  int gemm_variant = 3;               // encoder GEMM tile selection (3 = auto); changed only by mia_whisper_set_gemm_variant (tests)
   std::vector<void*> allocs;          // everything hipMalloc'ed for this handle (a clone owns only its batch buffers)
+  std::vector<void*> batch_allocs;    // the per-batch buffers of the current capacity (replaced as a set by whisper_reserve)
   mia_whisper* parent = nullptr;      // clone: the handle whose weights are shared (read-only)
   int n_clones = 0;                   // live clones of this handle: it cannot be freed before them
 

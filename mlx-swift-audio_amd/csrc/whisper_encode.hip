@@ -11,9 +11,7 @@
 namespace {
 
 int gemm(mia_whisper* w, GemmArgs g, int cls = MIA_PROF_ENC_GEMM) {
-  const char* fv = getenv("MIA_GEMM_VARIANT");   // test hook: force a tile variant (0/1: 128^2, 2: 256^2)
-  const int forced = fv ? atoi(fv) : -1;
-  if (forced >= 0) g.variant = forced;
+  g.variant = w->gemm_variant;
   if (const char* e = mia_gemm_check(g)) return mia_fail(w->ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
   const int rec = mia_prof_begin(w->ctx, cls, 2.0 * g.M * (double)g.N * g.K * (g.batch > 0 ? g.batch : 1));
   const int rc = mia_gemm_launch(g, w->dtype, w->ctx->stream);
@@ -30,70 +28,92 @@ int norm(mia_whisper* w, const LNW& ln, void* out, int M, int D) {
   return MIA_OK;
 }
 
-template <typename P>
-int alloc(mia_whisper* w, P*& p, size_t bytes, bool zero) {
-  void* q = nullptr;
-  if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess)
-    return mia_fail(w->ctx, MIA_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed for batch buffers", bytes);
-  w->allocs.push_back(q);
-  if (zero && hipMemsetAsync(q, 0, bytes, w->ctx->stream) != hipSuccess) return mia_fail(w->ctx, MIA_ERR_DEVICE, "memset failed");
-  p = (P*)q;
-  return MIA_OK;
-}
-
 }  // namespace
 
-// (Re)allocate every per-batch buffer for capacity B.  Buffers only grow; old ones are released at mia_whisper_free.
+// (Re)allocate every per-batch buffer for capacity B.  Transactional: the new set is allocated into a scratch copy of the handle's
+// pointers and committed only when every allocation has succeeded; the superseded set is freed after the stream has drained
+// (nothing on the device can still read it) and the captured step graph, which holds the old pointers, is invalidated first.
 int whisper_reserve(mia_whisper* w, int B) {
   if (B <= w->cap_B) return MIA_OK;
   MIA_HIP(w->ctx, hipStreamSynchronize(w->ctx->stream));
+  w->graph_valid = false;
   const mia_whisper_dims& d = w->dims;
   const size_t D = d.n_audio_state, T = d.n_audio_ctx, H = d.n_audio_head, L = d.n_text_layer;
   const size_t M = (size_t)B * T;
-  w->Tpad = (int)align_up(T, 64);
-  int rc;
-#define A(p, bytes, zero) if ((rc = alloc(w, p, (bytes), (zero))) != MIA_OK) return rc
-  A(w->mel_pad, ((size_t)B * (2 * T + 2) * d.n_mels + 256) * 2, true);
-  A(w->conv1_out, (size_t)B * (2 * T + 1) * D * 2, true);
-  A(w->x, M * D * 4, false);
-  A(w->h, M * D * 2, false);
-  A(w->qk, M * 2 * D * 2, false);
-  A(w->vt, (size_t)B * H * 64 * w->Tpad * 2, true);
-  A(w->att, M * D * 2, false);
-  A(w->g, M * 4 * D * 2, false);
-  A(w->feat, M * D * 2, false);
-  A(w->cross_k, L * M * D * 2, false);
-  A(w->cross_v, L * M * D * 2, false);
+  const int Tpad = (int)align_up(T, 64);
+  std::vector<void*> fresh;
+  bool ok = true;
+  auto get = [&](size_t bytes, bool zero) -> void* {
+    if (!ok) return nullptr;
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) { ok = false; mia_fail(w->ctx, MIA_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed for batch buffers", bytes); return nullptr; }
+    fresh.push_back(q);
+    if (zero && hipMemsetAsync(q, 0, bytes, w->ctx->stream) != hipSuccess) { ok = false; mia_fail(w->ctx, MIA_ERR_DEVICE, "memset failed"); }
+    return q;
+  };
+  mia_whisper n = *w;   // scratch copy of the pointer set (vectors are copied too; only the raw pointers below are used)
+#define A(p, bytes, zero) n.p = (decltype(n.p))get((bytes), (zero))
+  A(mel_pad, ((size_t)B * (2 * T + 2) * d.n_mels + 256) * 2, true);
+  A(conv1_out, (size_t)B * (2 * T + 1) * D * 2, true);
+  A(x, M * D * 4, false);
+  A(h, M * D * 2, false);
+  A(qk, M * 2 * D * 2, false);
+  A(vt, (size_t)B * H * 64 * Tpad * 2, true);
+  A(att, M * D * 2, false);
+  A(g, M * 4 * D * 2, false);
+  A(feat, M * D * 2, false);
+  A(cross_k, L * M * D * 2, false);
+  A(cross_v, L * M * D * 2, false);
   // decoder
   const size_t C = d.n_text_ctx, V = d.n_vocab;
-  A(w->self_k, L * B * C * D * 2, true);
-  A(w->self_v, L * B * C * D * 2, true);
-  A(w->dx, (size_t)B * D * 4, false);
-  A(w->dh, (size_t)B * D * 2, false);
-  A(w->dq, (size_t)B * D * 2, false);
-  A(w->da, (size_t)B * D * 2, false);
-  A(w->dg, (size_t)B * 4 * D * 2, false);
-  A(w->partial, (size_t)16 * B * D * 4, false);
-  A(w->logits, (size_t)B * V * 4, false);
-  A(w->tokens, (size_t)B * C * 4, true);
-  A(w->n_gen, (size_t)B * 4, true);
-  A(w->finished, (size_t)B * 4, true);
-  A(w->last_ts, (size_t)B * 4, true);
-  A(w->out_n, (size_t)B * 4, true);
-  A(w->sum_logprob, (size_t)B * 4, true);
-  A(w->n_logprob, (size_t)B * 4, true);
-  A(w->no_speech, (size_t)B * 4, true);
-  A(w->uniforms, (size_t)B * C * 4, true);
-  A(w->out_tokens, (size_t)B * C * 4, true);
-  A(w->out_avg, (size_t)B * 4, true);
-  if (!w->suppress_bits) { A(w->suppress_bits, 2 * ((V + 31) / 32) * 4, true); }
-  A(w->clip.pos, (size_t)B * 4, true);
-  A(w->clip.n_init, (size_t)B * 4, true);
-  A(w->clip.sot_idx, (size_t)B * 4, true);
-  A(w->clip.temp, (size_t)B * 4, true);
+  A(self_k, L * B * C * D * 2, true);
+  A(self_v, L * B * C * D * 2, true);
+  A(dx, (size_t)B * D * 4, false);
+  A(dh, (size_t)B * D * 2, false);
+  A(dq, (size_t)B * D * 2, false);
+  A(da, (size_t)B * D * 2, false);
+  A(dg, (size_t)B * 4 * D * 2, false);
+  A(partial, (size_t)16 * B * D * 4, false);
+  A(logits, (size_t)B * V * 4, false);
+  A(tokens, (size_t)B * C * 4, true);
+  A(n_gen, (size_t)B * 4, true);
+  A(finished, (size_t)B * 4, true);
+  A(last_ts, (size_t)B * 4, true);
+  A(out_n, (size_t)B * 4, true);
+  A(sum_logprob, (size_t)B * 4, true);
+  A(n_logprob, (size_t)B * 4, true);
+  A(no_speech, (size_t)B * 4, true);
+  A(uniforms, (size_t)B * C * 4, true);
+  A(out_tokens, (size_t)B * C * 4, true);
+  A(out_avg, (size_t)B * 4, true);
+  A(clip.pos, (size_t)B * 4, true);
+  A(clip.n_init, (size_t)B * 4, true);
+  A(clip.sot_idx, (size_t)B * 4, true);
+  A(clip.temp, (size_t)B * 4, true);
 #undef A
+  if (ok && hipStreamSynchronize(w->ctx->stream) != hipSuccess) { ok = false; mia_fail(w->ctx, MIA_ERR_DEVICE, "stream sync failed"); }
+  if (!ok) {
+    for (void* q : fresh) (void)hipFree(q);
+    return w->ctx->err.find("hipMalloc") != std::string::npos ? MIA_ERR_OUT_OF_MEMORY : MIA_ERR_DEVICE;
+  }
+  if (!w->suppress_bits) {   // vocabulary-sized, independent of B: allocated once, lives with the handle
+    void* q = nullptr;
+    const size_t bytes = 2 * ((V + 31) / 32) * 4;
+    if (hipMalloc(&q, bytes) != hipSuccess) { for (void* f : fresh) (void)hipFree(f); return mia_fail(w->ctx, MIA_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", bytes); }
+    (void)hipMemsetAsync(q, 0, bytes, w->ctx->stream);
+    w->allocs.push_back(q);
+    w->suppress_bits = (uint32_t*)q;
+  }
+  // commit: raw pointers from the scratch copy, then retire the superseded set (the stream is idle)
+  w->mel_pad = n.mel_pad; w->conv1_out = n.conv1_out; w->x = n.x; w->h = n.h; w->qk = n.qk; w->vt = n.vt; w->att = n.att; w->g = n.g;
+  w->feat = n.feat; w->cross_k = n.cross_k; w->cross_v = n.cross_v; w->self_k = n.self_k; w->self_v = n.self_v; w->dx = n.dx; w->dh = n.dh;
+  w->dq = n.dq; w->da = n.da; w->dg = n.dg; w->partial = n.partial; w->logits = n.logits; w->tokens = n.tokens; w->n_gen = n.n_gen;
+  w->finished = n.finished; w->last_ts = n.last_ts; w->out_n = n.out_n; w->sum_logprob = n.sum_logprob; w->n_logprob = n.n_logprob;
+  w->no_speech = n.no_speech; w->uniforms = n.uniforms; w->out_tokens = n.out_tokens; w->out_avg = n.out_avg; w->clip = n.clip;
+  for (void* q : w->batch_allocs) (void)hipFree(q);
+  w->batch_allocs.swap(fresh);
+  w->Tpad = Tpad;
   w->cap_B = B;
-  w->graph_valid = false;
   return MIA_OK;
 }
 
@@ -231,5 +251,14 @@ extern "C" int mia_whisper_get_audio_features(mia_whisper* w, void* out, int dty
   }
   MIA_HIP(ctx, hipMemcpyAsync(out, src, bytes, mem == MIA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
   if (mem == MIA_MEM_HOST) MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MIA_OK;
+}
+
+// Test hook (tests/test_whisper_gpu.py): force the encoder GEMM tile variant so that every kernel is exercised at reduced sizes.
+// 0 / 1: 128^2 tile (register / LDS-DMA staged), 2: 256^2 two-buffer, 3: auto (default), 4: 256^2 8-phase.
+extern "C" int mia_whisper_set_gemm_variant(mia_whisper* w, int variant) {
+  if (!w) return MIA_ERR_MODEL_NOT_LOADED;
+  MIA_CHECK_ARG(w->ctx, variant >= 0 && variant <= 4, "set_gemm_variant: variant must be 0..4 (got %d)", variant);
+  w->gemm_variant = variant;
   return MIA_OK;
 }

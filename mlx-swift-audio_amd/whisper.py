@@ -158,6 +158,13 @@ class WhisperModel:
             self.ctx.lib.mia_whisper_free(self.h)
             self.h = None
 
+    def set_gemm_variant(self, variant: int) -> None:
+        """Test hook: force the encoder GEMM tile variant (0/1: 128^2, 2: 256^2 two-buffer, 3: auto, 4: 256^2 8-phase)."""
+        lib = self.ctx.lib
+        lib.mia_whisper_set_gemm_variant.restype = C.c_int
+        lib.mia_whisper_set_gemm_variant.argtypes = [C.c_void_p, C.c_int]
+        self.ctx.check(lib.mia_whisper_set_gemm_variant(self.h, int(variant)))
+
     def clone(self, ctx: "_lib.Context") -> "WhisperModel":
         """A second handle on the same weights with its own batch state, bound to `ctx` (another stream of the same device)."""
         lib = ctx.lib
@@ -302,15 +309,12 @@ class WhisperModel:
 
 
     def transcribe_windows_device(self, pcm_ptr: int, offs: np.ndarray, o: DecodingOptions, tokens_ptr: int, n_ptr: int,
-                                  avg_ptr: int, nsp_ptr: int, pad_right: int = _audio.N_SAMPLES, _cache={}) -> None:
+                                  avg_ptr: int, nsp_ptr: int, pad_right: int = _audio.N_SAMPLES) -> None:
         """Same as transcribe_windows but every buffer already lives in HBM (raw device pointers, e.g. torch
         tensor.data_ptr()); nothing is copied and the call only enqueues work on the ctx stream (plus the small
         host syncs of the decode loop's early-exit poll)."""
         offs = np.ascontiguousarray(offs, np.int64)
-        key = id(o)
-        if key not in _cache:
-            _cache[key] = self._opts(o)
-        co, keep = _cache[key]
+        co, keep = self._opts(o)     # three small arrays: rebuilt per call, so mutating `o` between calls takes effect
         self.B = len(offs) - 1
         self.ctx.check(self.ctx.lib.mia_whisper_transcribe_windows(self.h, pcm_ptr, offs.ctypes.data, self.B, pad_right, C.byref(co),
                                                                    tokens_ptr, n_ptr, avg_ptr, nsp_ptr, _lib.MEM_DEVICE))

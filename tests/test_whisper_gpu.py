@@ -52,11 +52,13 @@ def test_encoder_matches_oracle(ctx, dims_name, dtype_name):
     model.close()
 
 
-@pytest.mark.parametrize("variant", ["0", "2"])
-def test_encoder_forced_tile_variants(ctx, variant, monkeypatch):
-    """The 256^2 tile (and its operand-swapped V path) is only auto-selected at full size: force it on the reduced model."""
-    monkeypatch.setenv("MIA_GEMM_VARIANT", variant)
+@pytest.mark.parametrize("variant", [0, 2, 4])
+def test_encoder_forced_tile_variants(ctx, variant):
+    """The 256^2 tiles (and their operand-swapped V path) are only auto-selected at full size: force them on the reduced model."""
     dims, oracle, model = _models(ctx, "micro", "f16", seed=6)
+    model.set_gemm_variant(variant)
+    with pytest.raises(m.MiaError):
+        model.set_gemm_variant(5)
     mel = _mel(dims, 5, 2, "f16")
     model.encode(mel)
     got = model.audio_features()
