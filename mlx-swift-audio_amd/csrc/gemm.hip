@@ -620,6 +620,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
   f32x4 bias4[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) bias4[nt] = load_bias4(g, n0 + wc * 64 + nt * 16 + e_n);
+  if constexpr (!OUT_F32 && (EPI == MIA_EPI_STD || EPI == MIA_EPI_QKV_VT)) {
+    // 16-bit row-major output: the direct store is 32 x 8 B per lane in 32-B row pieces and is store-ISSUE-bound (a third of a
+    // K = 1280 tile's time).  Stage the wave's 128 x 64 sub-tile in its own 16 KB of the (now idle) LDS -- 128-B rows, 16-B chunk
+    // XOR (row & 7) -- and write it out as 16 x 16 B per lane: whole 128-B row segments, half the store instructions.
+    const bool rows16 = g.R == nullptr && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (((uintptr_t)g.C) & 15) == 0 && (g.strideC & 7) == 0 &&
+                        (EPI == MIA_EPI_STD || n0 + BN2 <= 2 * g.H * 64);
+    if (rows16) {
+      char* reg = lds + wave * 16384;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int row = mt * 16 + e_m;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(acc[mt][nt][j] + bias4[nt][j], g.act);
+          const int c16 = nt * 2 + (lane >> 5), half = (lane >> 4) & 1;
+          *reinterpret_cast<u32x2*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4) + half * 8) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+        }
+      }
+      uint16_t* cb = reinterpret_cast<uint16_t*>(g.C) + (EPI == MIA_EPI_STD ? (int64_t)bz * g.strideC : 0);
+      const int c16 = lane & 7;
+      const int n = n0 + wc * 64 + c16 * 8;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 8 * i + (lane >> 3);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4));
+        const int m = m0 + wr * 128 + row;
+        if (m < g.M && n < g.N) *reinterpret_cast<u32x4*>(cb + (int64_t)m * g.ldc + n) = v;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int m = m0 + wr * 128 + mt * 16 + e_m;

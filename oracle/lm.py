@@ -138,14 +138,39 @@ def sample_with_uniform(filtered_logits: np.ndarray, u: float) -> int:
     return int(np.searchsorted(c, u * c[-1], side="right"))
 
 
-def generate(model: LMOracle, prompt, sampler, uniforms) -> list[int]:
-    """generateChunk's loop (OrpheusTTS.swift:245-348) with the explicit-uniform categorical."""
+def sample_boundary_distance(logits: np.ndarray, history, rep_penalty: float, temperature: float, top_p: float, u: float) -> tuple[float, float]:
+    """Oracle-only diagnostic for one sampler step: (distance of u to the nearest edge of the chosen token's CDF interval,
+    distance of the nearest sorted cumulative probability to top_p).  A 16-bit build may legitimately pick another token only
+    when one of the two is within its rounding noise."""
+    f = top_p_filter(logits, history, rep_penalty, temperature, top_p)
+    tok = sample_with_uniform(f, u)
+    x = np.asarray(f, np.float64)
+    p = np.exp(x - x[np.isfinite(x)].max())
+    p[~np.isfinite(x)] = 0.0
+    c = np.cumsum(p) / p.sum()
+    lo = c[tok - 1] if tok > 0 else 0.0
+    cdf_d = float(min(u - lo, c[tok] - u))
+    lg = np.asarray(logits, np.float64).copy()
+    if rep_penalty != 1.0 and len(history) > 0:
+        idx = np.asarray(history, np.int64)
+        lg[idx] = np.where(lg[idx] < 0, lg[idx] * rep_penalty, lg[idx] / rep_penalty)
+    lg = lg / max(temperature, 1e-6)
+    q = np.exp(lg - lg.max()); q /= q.sum()
+    cum = np.cumsum(np.sort(q)[::-1])
+    return cdf_d, float(np.abs(cum - top_p).min())
+
+
+def generate(model: LMOracle, prompt, sampler, uniforms, trace: list | None = None) -> list[int]:
+    """generateChunk's loop (OrpheusTTS.swift:245-348) with the explicit-uniform categorical.  `trace` (oracle-only) receives one
+    sample_boundary_distance() pair per step."""
     model.reset()
     logits = model.forward(prompt)[-1].numpy()
     out, hist = [], []
     for i in range(sampler["max_new_tokens"]):
         f = top_p_filter(logits, hist, sampler["rep_penalty"], sampler["temperature"], sampler["top_p"])
         nxt = sample_with_uniform(f, float(uniforms[i]))
+        if trace is not None:
+            trace.append(sample_boundary_distance(logits, hist, sampler["rep_penalty"], sampler["temperature"], sampler["top_p"], float(uniforms[i])))
         out.append(nxt)
         if nxt in sampler["stop_ids"]:
             break

@@ -63,7 +63,7 @@ class S3Oracle:
         return x + g @ W[p + ".mlp.layers.2.weight"].t() + W[p + ".mlp.layers.2.bias"]
 
     def quantize(self, mel: np.ndarray, mel_len: np.ndarray):
-        """mel [B, n_mels, T], mel_len [B] (all <= 3000 frames) -> (codes int32 [B, T''], code_len [B])."""
+        """mel [B, n_mels, T], mel_len [B] (all <= 3000 frames) -> (codes int32 [B, T''], code_len [B], pre-round FSQ values [B, T'', 8])."""
         W = self.w
         x = _t(mel)
         lens = torch.as_tensor(np.asarray(mel_len, np.int64))
@@ -81,11 +81,11 @@ class S3Oracle:
         mask_bias = ((1.0 - m) * -1.0e10)[:, None, :]
         for l in range(self.cfg.n_audio_layer):
             x = self._block(f"encoder.blocks.{l}", x, mask_bias, mask_pad)
-        h = torch.tanh(x @ W["quantizer.fsq_codebook.project_down.weight"].t() + W["quantizer.fsq_codebook.project_down.bias"])
-        h = torch.round(h * 0.9990000128746033) + 1                       # torch.round is half-to-even like MLX
+        pre = torch.tanh(x @ W["quantizer.fsq_codebook.project_down.weight"].t() + W["quantizer.fsq_codebook.project_down.bias"]) * 0.9990000128746033
+        h = torch.round(pre) + 1                                          # torch.round is half-to-even like MLX
         powers = torch.pow(torch.tensor(3.0), torch.arange(8, dtype=torch.float32))
         ids = torch.sum(h * powers[None, None, :], dim=-1).to(torch.int32)
-        return ids.numpy(), lens.numpy().astype(np.int32), h.numpy()
+        return ids.numpy(), lens.numpy().astype(np.int32), pre.numpy()     # pre: the PRE-round FSQ values (tests prove boundary cases with them)
 
 
 def merge_tokenized_segments(segments: list[list[int]], overlap: int = 4, token_rate: int = 25) -> list[int]:

@@ -228,6 +228,8 @@ class DecodingResult:
     no_speech_prob: float
     margins: list[float]          # oracle-only diagnostic: top-1 minus top-2 filtered logit at every step
     initial_tokens: list[int]
+    cdf_margins: list = None      # oracle-only diagnostic (T > 0): distance of the step's uniform to the nearest edge of the chosen
+                                  # token's CDF interval, i.e. how far the 16-bit build's CDF may move before the draw changes
 
 
 def initial_tokens(st: SpecialTokens, o: DecodingOptions) -> tuple[list[int], int]:
@@ -264,6 +266,7 @@ def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: 
     kv = None
     sum_lp, count, no_speech_prob = 0.0, 0, 0.0
     margins: list[float] = []
+    cdf_margins: list[float] = []
     NEG = -float("inf")
     idx = torch.arange(V)
     for it in range(max_generate):
@@ -312,6 +315,7 @@ def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: 
         if force_ts:
             ts_mask[idx < tsb] = NEG
         last = last + torch.minimum(base, ts_mask)
+        cdf_m = float("inf")
         if o.temperature == 0.0:
             nxt = int(torch.argmax(last))
         elif not bool(torch.isfinite(last).any()):
@@ -319,6 +323,10 @@ def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: 
         else:
             probs = torch.softmax(last / o.temperature, dim=-1).numpy()            # :335-338
             nxt = sample_from_distribution(probs, float(uniforms[it]))
+            c = np.cumsum(probs.astype(np.float64))
+            lo = c[nxt - 1] if nxt > 0 else 0.0
+            cdf_m = float(min(float(uniforms[it]) - lo, c[nxt] - float(uniforms[it])))
+        cdf_margins.append(cdf_m)
         top2 = torch.topk(last, 2).values
         margins.append(float(top2[0] - top2[1]))
         if nxt != st.eot:                                                # :345-350
@@ -332,7 +340,7 @@ def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: 
     gen = tokens[initial_count:]
     if st.eot in gen:
         gen = gen[:gen.index(st.eot)]
-    return DecodingResult(gen, avg, no_speech_prob, margins, init)
+    return DecodingResult(gen, avg, no_speech_prob, margins, init, cdf_margins)
 
 
 # ---- word timestamps: WhisperTiming.swift (dtw :46-130, medianFilterAttention :191-253, findAlignment :558-748) ----------------------

@@ -14,14 +14,23 @@ from mlx_swift_audio_amd import synthetic as S
 pytestmark = pytest.mark.gpu
 
 
-def test_whisper_large_v3_turbo_full_size(ctx):
+@pytest.fixture(scope="module")
+def turbo(ctx):
+    """One large-v3-turbo checkpoint (bf16-rounded, shared by the HIP model and the oracle) for the tests of this module."""
     import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import whisper as HW
+    dims = S.DIMS["large-v3-turbo"]
+    weights = S.synthetic_weights(dims, seed=0, style="survey", round_to="bf16")
+    model = HW.WhisperModel.load(ctx, dims, weights, m.BF16)
+    yield dims, weights, model
+    model.close()
+
+
+def test_whisper_large_v3_turbo_full_size(ctx, turbo):
     from mlx_swift_audio_amd import whisper as HW
     from oracle import logmel as OL
     from oracle import whisper as OW
-    dims = S.DIMS["large-v3-turbo"]
-    weights = S.synthetic_weights(dims, seed=0, style="survey", round_to="bf16")      # one checkpoint for both sides
-    model = HW.WhisperModel.load(ctx, dims, weights, m.BF16)
+    dims, weights, model = turbo
     n_new = 12
     o = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(model.special), blank_ids=[220], max_new_tokens=n_new)
     clips = [S.synth_clip(i) for i in range(4)]
@@ -48,7 +57,45 @@ def test_whisper_large_v3_turbo_full_size(ctx):
     again = model.transcribe_windows(clips, o)
     assert [r.tokens for r in again] == [r.tokens for r in batch]                             # determinism
     assert all(len(r.tokens) == n_new for r in batch)                                          # random weights never emit EOT early
-    model.close()
+
+
+def test_whisper_turbo_headline_batch_32(ctx, turbo):
+    """The configuration bench.py times: 32 x 30 s clips in ONE batch (M = 48 000 rows -> the 256^2 8-phase GEMM tile, the 32-row
+    skinny decode tile), 64 generated tokens.  Two of the 32 clips are checked against the fp32 oracle at full size (encoder
+    features + every token under the margin rule); all 32 are checked through batch invariance against runs of 4 clips
+    (M = 6 000 rows -> the 128^2 tile): per-clip token ids must be identical whatever batch, tile shape or row slot a clip has."""
+    from mlx_swift_audio_amd import whisper as HW
+    from oracle import logmel as OL
+    from oracle import whisper as OW
+    dims, weights, model = turbo
+    n_new = 64
+    o = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(model.special), blank_ids=[220], max_new_tokens=n_new)
+    clips = [S.synth_clip(i) for i in range(32)]
+    big = model.transcribe_windows(clips, o)
+    feats = model.audio_features()
+    assert all(len(r.tokens) == n_new for r in big)
+    ora = OW.WhisperOracle(dims, weights)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    oo = OW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=n_new)
+    for b in (5, 30):
+        mel = OW.round_array(OL.whisper_log_mel_spectrogram(clips[b], dims.n_mels, padding=OL.N_SAMPLES)[:OL.N_FRAMES], "bf16")[None]
+        xa = ora.encode(mel)
+        ref_feats = xa.numpy()[0]
+        scale = np.abs(ref_feats).max()
+        assert np.abs(feats[b] - ref_feats).max() <= 0.03 * scale, (b, np.abs(feats[b] - ref_feats).max(), scale)
+        ref = OW.greedy_decode(ora, st, xa, oo)
+        k = next((i for i, (a, c) in enumerate(zip(big[b].tokens, ref.tokens)) if a != c), min(len(big[b].tokens), len(ref.tokens)))
+        assert k == len(ref.tokens) or ref.margins[k] < 0.05, (b, k, ref.margins[k], big[b].tokens[:k + 2], ref.tokens[:k + 2])
+        assert k >= 8, (b, k)          # a fork inside the first steps would point at the kernels, not at bf16 noise
+    # batch invariance.  The encoder's M-tile shape differs between the two runs (fp32 summation order inside a K-tile does not:
+    # both tiles accumulate k in the same order), so ids must be IDENTICAL; encoder features are compared bit for bit too.
+    for i in range(0, 32, 4):
+        small = model.transcribe_windows(clips[i:i + 4], o)
+        fs = model.audio_features()
+        for j in range(4):
+            assert small[j].tokens == big[i + j].tokens, (i + j,)
+            assert np.array_equal(np.float32(small[j].avg_logprob), np.float32(big[i + j].avg_logprob), equal_nan=True)
+        np.testing.assert_array_equal(fs, feats[i:i + 4])
 
 
 def test_qwen2_half_billion_full_size(ctx):

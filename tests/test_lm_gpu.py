@@ -12,6 +12,8 @@ from oracle import lm as OL
 
 pytestmark = pytest.mark.gpu
 
+SAMPLE_TOL = 5e-3    # f16 parity mode: |logit error| / T at these dims stays well below this
+
 
 def _dt(name):
     import mlx_swift_audio_amd as m
@@ -116,10 +118,14 @@ def test_generate_matches_oracle(ctx, cfg_name):
     u = np.random.default_rng(3).random(n_new).astype(np.float32)
     stop = 2999
     got = model.generate(prompt, u, temperature=0.6, top_p=0.8, rep_penalty=1.3, rep_window=20, max_new_tokens=n_new, stop_ids=(stop,))
-    ref = OL.generate(ora, prompt, {"temperature": 0.6, "top_p": 0.8, "rep_penalty": 1.3, "rep_window": 20, "max_new_tokens": n_new, "stop_ids": (stop,)}, u)
-    # a first divergence is tolerated only where the f16 logit noise can move a boundary; require a long exact prefix
+    trace = []
+    ref = OL.generate(ora, prompt, {"temperature": 0.6, "top_p": 0.8, "rep_penalty": 1.3, "rep_window": 20, "max_new_tokens": n_new, "stop_ids": (stop,)}, u, trace)
+    # a first divergence is legal only at a step where the ORACLE's own draw is within the f16 logit noise of flipping: the uniform
+    # within SAMPLE_TOL of an edge of the chosen token's CDF interval, or a sorted cumulative probability within SAMPLE_TOL of top_p
     k = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
-    assert k >= 8, (got, ref)
+    if not (k == len(got) == len(ref)):
+        cdf_d, topp_d = trace[k]
+        assert min(cdf_d, topp_d) < SAMPLE_TOL, (k, cdf_d, topp_d, got, ref)
     model.close()
 
 

@@ -1,6 +1,6 @@
 """GPU parity: S3Tokenizer (HIP fp32, exact-length per clip) vs the fp32 CPU oracle that follows the Swift's padded-batch +
-mask arithmetic.  Token ids must be bit-exact wherever the oracle's pre-round FSQ value tanh(.)*0.999 is farther than 2e-3
-from a rounding boundary (+-0.5); the test asserts the match rate and that every mismatch sits on such a boundary."""
+mask arithmetic.  Token ids (integers) must be bit-exact; a base-3 digit may differ ONLY where the oracle's own pre-round FSQ
+value tanh(.)*0.999 lies within BOUNDARY_TOL of a rounding boundary (+-0.5), which the test proves digit by digit."""
 import numpy as np
 import pytest
 
@@ -9,6 +9,21 @@ from oracle import logmel as OL
 from oracle import s3tok as OS
 
 pytestmark = pytest.mark.gpu
+
+BOUNDARY_TOL = 2e-3
+
+
+def assert_ids_exact_or_on_boundary(got, ref, pre, what=""):
+    """got / ref: int ids [T]; pre: oracle pre-round values [T, 8].  Every digit that differs must sit on a rounding boundary."""
+    bad = 0
+    for t in np.nonzero(np.asarray(got) != np.asarray(ref))[0]:
+        bad += 1
+        for i in range(8):
+            dg, dr = (int(got[t]) // 3 ** i) % 3, (int(ref[t]) // 3 ** i) % 3
+            if dg != dr:
+                dist = abs(abs(float(pre[t, i])) - 0.5)
+                assert abs(dg - dr) == 1 and dist < BOUNDARY_TOL, f"{what} t={t} digit {i}: {dg} vs {dr}, pre-round {pre[t, i]} is {dist} from +-0.5"
+    return bad
 
 
 def _prepare(ctx, cfg_name, seed):
@@ -31,20 +46,11 @@ def test_tokens_match_oracle_ragged_batch(ctx):
         mel[b, :, :m.shape[1]] = m
         mel_len.append(m.shape[1])
     got, n = tok.quantize(mel, mel_len)
-    ref, rn, h = ora.quantize(mel, np.asarray(mel_len))
+    ref, rn, pre = ora.quantize(mel, np.asarray(mel_len))
     np.testing.assert_array_equal(n, rn)
-    total = bad = 0
     for b in range(3):
-        for t in range(n[b]):
-            total += 1
-            if got[b, t] != ref[b, t]:
-                bad += 1
-                # the pre-round values of the differing digits must sit on a rounding boundary
-                digits_g = [(got[b, t] // 3 ** i) % 3 for i in range(8)]
-                digits_r = [(ref[b, t] // 3 ** i) % 3 for i in range(8)]
-                assert sum(a != c for a, c in zip(digits_g, digits_r)) <= 2
+        assert_ids_exact_or_on_boundary(got[b, :n[b]], ref[b, :n[b]], pre[b], f"clip {b}")
         assert np.all(got[b, n[b]:] == 0)
-    assert bad / total <= 0.02, (bad, total)
     tok.close()
 
 
@@ -54,18 +60,39 @@ def test_long_audio_windows_and_merge(ctx):
     L = 3000 + 2600 + 700                                        # three windows
     mel = (0.5 * rng.standard_normal((1, cfg.n_mels, L))).astype(np.float32)
     got, n = tok.quantize(mel, [L])
-    segs, start = [], 0
+    segs, pres, start = [], [], 0
     while start < L:
         end = min(start + 3000, L)
-        ids, ln, _ = ora.quantize(mel[:, :, start:end], np.asarray([end - start]))
+        ids, ln, pre = ora.quantize(mel[:, :, start:end], np.asarray([end - start]))
         segs.append(ids[0, :ln[0]].tolist())
+        pres.append([pre[0, t] for t in range(ln[0])])
         if end == L:
             break
         start += 2600
     ref = OS.merge_tokenized_segments(segs)
+    ref_pre = np.asarray(OS.merge_tokenized_segments(pres))       # the same slicing applied to the pre-round rows
     assert n[0] == len(ref)
-    match = np.mean(np.asarray(ref) == got[0, :n[0]])
-    assert match >= 0.98, match
+    assert_ids_exact_or_on_boundary(got[0, :n[0]], np.asarray(ref), ref_pre, "long audio")
+    tok.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["s3_v2", "s3_v3"])
+def test_real_geometry_tokens_match_oracle(ctx, cfg_name):
+    """S3TokenizerV2 / V3 at their real width and depth (d 1280, 20 heads, 6 / 12 FSMN blocks) on a few seconds of input."""
+    from mlx_swift_audio_amd import audio as A
+    cfg, tok, ora = _prepare(ctx, cfg_name, 4)
+    clips = [OL.synth_clip(5, 16000 * 3), OL.synth_clip(6, 16000 * 2 + 777)]
+    mels = [A.s3_log_mel_spectrogram(ctx, c, cfg.n_mels) for c in clips]
+    T = max(m.shape[1] for m in mels)
+    mel = np.zeros((2, cfg.n_mels, T), np.float32)
+    for b, m in enumerate(mels):
+        mel[b, :, :m.shape[1]] = m
+    lens = [m.shape[1] for m in mels]
+    got, n = tok.quantize(mel, lens)
+    ref, rn, pre = ora.quantize(mel, np.asarray(lens))
+    np.testing.assert_array_equal(n, rn)
+    bad = sum(assert_ids_exact_or_on_boundary(got[b, :n[b]], ref[b, :n[b]], pre[b], f"{cfg_name} clip {b}") for b in range(2))
+    assert bad <= 0.05 * int(n.sum()), (bad, int(n.sum()))       # boundary cases are rare by construction
     tok.close()
 
 

@@ -5,6 +5,7 @@ precision and accumulation order differ.  Tolerances (stated, checked below):
   audio features (post-LayerNorm, O(1)):  max |err| <= 0.06 (bf16) / 0.01 (f16); mean |err| <= 0.008 / 0.0015
   greedy token ids: bit-exact, except that a first divergence is tolerated only where the oracle's own top-1/top-2
   margin is below MARGIN_TOL (a near-tie that 16-bit activations cannot resolve); the golden case must match fully.
+  sampled (T > 0) ids: same rule with the oracle's CDF-edge distance (CDF_TOL) in place of the logit margin.
 """
 import numpy as np
 import pytest
@@ -15,6 +16,9 @@ from oracle import whisper as OW
 pytestmark = pytest.mark.gpu
 
 MARGIN_TOL = {"bf16": 0.15, "f16": 0.03}
+# T > 0: the sampled id may differ only where the step's uniform lies this close to an edge of the chosen token's CDF interval in
+# the ORACLE (the 16-bit build's CDF is the oracle's moved by at most max|logit error| / T; same scale as MARGIN_TOL)
+CDF_TOL = {"bf16": 0.05, "f16": 0.01}
 
 
 def _dt(name):
@@ -55,6 +59,7 @@ def test_encoder_matches_oracle(ctx, dims_name, dtype_name):
 @pytest.mark.parametrize("variant", [0, 2, 4])
 def test_encoder_forced_tile_variants(ctx, variant):
     """The 256^2 tiles (and their operand-swapped V path) are only auto-selected at full size: force them on the reduced model."""
+    import mlx_swift_audio_amd as m
     dims, oracle, model = _models(ctx, "micro", "f16", seed=6)
     model.set_gemm_variant(variant)
     with pytest.raises(m.MiaError):
@@ -181,18 +186,19 @@ def test_ragged_prompts_and_sampling_match_oracle(ctx):
     sot_idx = [len(i) - 1 for i in inits]
     uni = np.random.default_rng(11).random((B, o.max_tokens)).astype(np.float32)
     res = model.decode_ragged(o, inits, sot_idx, temps, uni, active=[True, True, True, True])
-    n_exact = 0
     for b in range(B):
         oo = OW.DecodingOptions(timestamps=True, suppress_ids=sup, blank_ids=[220], max_new_tokens=20, prompt=prompts[b], temperature=temps[b])
         ref = OW.greedy_decode(oracle, st, xa[b:b + 1], oo, uniforms=uni[b])
         assert ref.initial_tokens == inits[b]
         k = next((i for i, (a, c) in enumerate(zip(res[b].tokens, ref.tokens)) if a != c), min(len(res[b].tokens), len(ref.tokens)))
-        if k == len(ref.tokens) == len(res[b].tokens):
-            n_exact += 1
-        else:
-            assert k >= 4, (b, res[b].tokens, ref.tokens)      # sampled streams can fork at a CDF boundary; never early
+        if not (k == len(ref.tokens) == len(res[b].tokens)):
+            # a fork is legal only where the ORACLE's own decision is within the 16-bit build's rounding noise of flipping:
+            # T = 0: top-1 / top-2 logit margin;  T > 0: distance of the uniform to the chosen token's CDF interval edge
+            if temps[b] == 0.0:
+                assert ref.margins[k] < MARGIN_TOL["f16"], (b, k, ref.margins[k], res[b].tokens, ref.tokens)
+            else:
+                assert ref.cdf_margins[k] < CDF_TOL["f16"], (b, k, ref.cdf_margins[k], res[b].tokens, ref.tokens)
         np.testing.assert_allclose(res[b].no_speech_prob, ref.no_speech_prob, rtol=0.1, atol=1e-6)
-    assert n_exact >= 2
     # inactive clips are left alone (no tokens), active ones reproduce the earlier result
     res2 = model.decode_ragged(o, inits, sot_idx, temps, uni, active=[True, False, False, True])
     assert res2[1].tokens == [] and res2[2].tokens == []
@@ -236,12 +242,12 @@ def test_transcribe_loop_hip_vs_oracle(ctx):
                               n_audio_ctx=dims.n_audio_ctx, **kw)
     for g, r in zip(got, ref):
         assert g.passes >= 1 and g.duration == r.duration
-        # identical control flow as long as the decoders agree; compare the first segments exactly
-        n = min(len(g.segments), len(r.segments))
-        assert n >= 1 or (len(g.segments) == len(r.segments) == 0)
-        if n:
-            assert g.segments[0].tokens == r.segments[0].tokens
-            assert abs(g.segments[0].start - r.segments[0].start) < 1e-6 and abs(g.segments[0].end - r.segments[0].end) < 1e-6
+        # identical control flow as long as the decoders agree: every segment (tokens, start, end) must be equal
+        assert len(g.segments) == len(r.segments), (len(g.segments), len(r.segments))
+        for sg, sr in zip(g.segments, r.segments):
+            assert sg.tokens == sr.tokens
+            assert abs(sg.start - sr.start) < 1e-6 and abs(sg.end - sr.end) < 1e-6
+        assert g.passes == r.passes
     model.close()
 
 
