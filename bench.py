@@ -65,6 +65,71 @@ def cpu_baseline(dims_name: str, seed: int, n_threads: int, max_new_tokens: int)
                        f"{n_tok} greedy steps {t3 - t2:.2f}s scaled to {full_tokens} steps")}
 
 
+def self_launch(n: int) -> int:
+    """Start n rank processes of this script on one node and wait for them; rank 0's JSON line goes to our stdout."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("MIA_BENCH_REHEARSAL") == "1"
+    if not rehearsal:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def config0_leg(ctx, torch, dtype_name: str = "f16"):
+    """BASELINE.json configs[0]: Whisper tiny.en, greedy transcribe of ONE 10 s mono clip (the reference's CPU-runnable plumbing case).
+    GPU: the same C-ABI path (log-mel + encode + 445-step decode, f16 like the reference's storage); CPU: the oracle at all cores
+    and at 1 thread, complete run, nothing extrapolated."""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import synthetic as S
+    from mlx_swift_audio_amd import whisper as HW
+    import torch as _t
+    from oracle import logmel as OL
+    from oracle import whisper as OW
+    dims = S.DIMS["tiny.en"]
+    weights = S.synthetic_weights(dims, seed=0, style="survey", round_to=dtype_name)
+    model = HW.WhisperModel.load(ctx, dims, weights, m.F16 if dtype_name == "f16" else m.BF16)
+    o = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(model.special), blank_ids=[220])
+    clip = S.synth_clip(0)[:160000]
+    model.transcribe_windows([clip], o)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        res = model.transcribe_windows([clip], o)[0]
+    gpu_s = (time.perf_counter() - t0) / reps
+    model.close()
+    out = {"workload": "Whisper tiny.en f16, one 10 s clip, log-mel + encode + greedy decode (445 generated tokens: random-init weights never emit EOT)",
+           "gpu": {"audio_s_per_s": round(10.0 / gpu_s, 1), "ms": round(gpu_s * 1e3, 2), "generated_tokens": len(res.tokens), "note": "host-inclusive wall clock (pcm and tokens cross PCIe)"}}
+    ora = OW.WhisperOracle(dims, weights)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    oo = OW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220])
+    ncpu = min(16, len(os.sched_getaffinity(0)))
+    for nt in (ncpu, 1):
+        _t.set_num_threads(nt)
+        t0 = time.perf_counter()
+        mel = OW.round_array(OL.whisper_log_mel_spectrogram(clip, dims.n_mels, padding=OL.N_SAMPLES)[:OL.N_FRAMES], dtype_name)[None]
+        r = OW.greedy_decode(ora, st, ora.encode(mel), oo)
+        dt = time.perf_counter() - t0
+        out[f"cpu_{nt}_threads" if nt != 1 else "cpu_1_thread"] = {"audio_s_per_s": round(10.0 / dt, 3), "s": round(dt, 2), "generated_tokens": len(r.tokens), "kind": "port"}
+    _t.set_num_threads(ncpu)
+    return out
+
+
 def lm_bench(ctx, torch, name: str, batch: int):
     """BASELINE.json configs[2] ("Orpheus-3B TTS: Llama-3 backbone autoregress + SNAC codec decode"), the LM half: random-init bf16
     weights, 64-token prompts, 210 sampled tokens (30 SNAC frames); one sequence, then `batch` sentences side by side.  Host-inclusive
@@ -259,7 +324,15 @@ def main():
     ap.add_argument("--lm-batch", type=int, default=32, help="sentences side by side in the batched part of --lm")
     ap.add_argument("--replicas", type=int, default=2,
                     help="model replicas on separate HIP streams; passes are dealt round-robin so the encoder of one batch overlaps the decoder of another (1 = strictly serial passes)")
+    ap.add_argument("--no-config0", action="store_true", help="skip the BASELINE configs[0] leg (tiny.en, one 10 s clip: GPU + CPU at all cores and 1 thread)")
+    ap.add_argument("--dp", default="abi", choices=["abi", "torch"], help="token all-gather at N > 1: mia_dp_* (RCCL behind the C ABI, one communicator per replica stream) or torch.distributed")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  This process starts N rank processes (one per GPU,
+        # RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and never touches a GPU itself -- counting devices does not
+        # initialise the runtime -- so no exec happens after HIP initialisation anywhere.
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -279,7 +352,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
     import mlx_swift_audio_amd as m
     from mlx_swift_audio_amd import synthetic as S
@@ -319,9 +393,24 @@ def main():
                 self.nsp = torch.zeros(B, dtype=torch.float32, device="cuda")
             self.stream.synchronize()
 
+            self.group = None          # torch.distributed group of this replica (fallback exchange)
+            self.dp_abi = False        # mia_dp_* communicator on this replica's context
+            if world > 1:
+                with torch.cuda.stream(self.stream):
+                    self.all_tokens = torch.zeros((B * world, self.opts.max_tokens), dtype=torch.int32, device="cuda")
+                    self.all_n = torch.zeros(B * world, dtype=torch.int32, device="cuda")
+                self.stream.synchronize()
+
         def step(self):
             self.model.transcribe_windows_device(pcm.data_ptr(), offs, self.opts, self.tokens.data_ptr(), self.n_tok.data_ptr(), self.avg.data_ptr(),
                                                  self.nsp.data_ptr())
+            if world > 1:              # the path's only exchange, once per pass, on this pass's buffers, behind the decode on the same stream
+                if self.dp_abi:
+                    P.dp_gather_tokens(self.ctx, self.tokens.data_ptr(), self.n_tok.data_ptr(), B, self.opts.max_tokens, B * world,
+                                       self.all_tokens.data_ptr(), self.all_n.data_ptr())
+                else:
+                    with torch.cuda.stream(self.stream):
+                        P.gather_tokens(self.tokens, self.n_tok, world, max_shard=B, group=self.group)
 
     R = max(1, min(args.replicas, args.steps))
     t0 = time.time()
@@ -330,6 +419,31 @@ def main():
     del weights
     log(f"[bench] {R} replica(s) loaded in {time.time() - t0:.1f}s")
     ctx = reps[0].ctx
+    dp_mode = "none"
+    if world > 1:
+        # one exchange channel per replica, so that the replicas' host threads never interleave collectives on a shared communicator
+        use_abi = args.dp == "abi" and not rehearsal
+        ok = torch.ones(1, dtype=torch.int32, device="cuda" if not rehearsal else "cpu")
+        if use_abi:
+            for rp in reps:
+                ids = [P.dp_unique_id(rp.ctx) if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                try:
+                    P.dp_init(rp.ctx, rank, world, ids[0])
+                    rp.dp_abi = True
+                except m.MiaError as e:
+                    log(f"[bench] rank {rank}: mia_dp_init failed ({e}); falling back to torch.distributed")
+                    ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not use_abi or int(ok.item()) == 0:
+            for rp in reps:
+                if rp.dp_abi:
+                    P.dp_shutdown(rp.ctx)
+                    rp.dp_abi = False
+                rp.group = dist.new_group(ranks=list(range(world)), backend="gloo" if rehearsal else "nccl")
+            dp_mode = "torch.distributed all_gather, one group per replica"
+        else:
+            dp_mode = "mia_dp_gather_tokens (RCCL behind the C ABI), one communicator per replica stream"
 
     def run_passes(k):
         """k passes dealt round-robin over the replicas, one host thread per replica; returns when every stream has drained."""
@@ -345,10 +459,7 @@ def main():
                 t.join()
         for rp in reps:
             rp.ctx.synchronize()
-        if world > 1:
-            for i in range(k):                    # the path's only exchange: token ids over xGMI (RCCL), one gather per pass
-                rp = reps[i % R]
-                P.gather_tokens(rp.tokens, rp.n_tok, world, max_shard=B)
+            rp.stream.synchronize()
 
     def fence():
         if world > 1:
@@ -358,18 +469,26 @@ def main():
     prof_keys = ("logmel", "enc_gemm", "crosskv_gemm", "enc_attention", "enc_norm", "decode")
     run_passes(max(args.warmup, 1) * R if args.warmup else 0)     # every replica captures its step graph during warm-up
     fence()
-    # ---- serial calibration pass (replica 0 alone): the uncontended per-launch figures of every kernel class
-    ctx.profile(True)
-    ctx.profile_reset()
-    reps[0].step()
-    ctx.synchronize()
-    prof_serial = {k: ctx.profile_read(k) for k in prof_keys}
-    fence()
-    # R == 1: the timed region itself is instrumented.  R > 1: a launch's wall duration under concurrent streams includes waiting for
-    # the other streams' kernels and says nothing about the kernel, so the timed region runs un-instrumented and `roofline` / `stages`
-    # come from the calibration pass above (same process, same workload, HIP events on the library's stream).
-    ctx.profile(False)
-    if R == 1:
+    # ---- serial execution (replica 0 alone, instrumented): `roofline` and `stages` describe THIS execution -- HIP events on the
+    # library's stream over whole passes with nothing else on the GPU, next to its own wall-clock throughput -- so that one set of
+    # numbers describes one execution.  (Under R concurrent streams a launch's wall duration includes waiting for the other streams'
+    # kernels and says nothing about the kernel; the pipelined timed region below therefore runs un-instrumented.)
+    n_serial = 1 if R == 1 else 2
+    serial_exec = None
+    if R > 1:
+        ctx.profile(True)
+        ctx.profile_reset()
+        fence()
+        ts = time.perf_counter()
+        for _ in range(n_serial):
+            reps[0].step()
+        ctx.synchronize()
+        reps[0].stream.synchronize()
+        serial_s = time.perf_counter() - ts
+        prof_serial = {k: ctx.profile_read(k) for k in prof_keys}
+        serial_exec = {"replicas": 1, "passes": n_serial, "ms_per_step": round(serial_s / n_serial * 1e3, 3), "value": round(30.0 * B * n_serial / serial_s, 2), "unit": "audio-sec/s"}
+        ctx.profile(False)
+    else:
         ctx.profile(True)
         ctx.profile_reset()
     fence()
@@ -391,7 +510,9 @@ def main():
     model = reps[0].model
 
     L, D, V, T = dims.n_text_layer, dims.n_text_state, dims.n_vocab, dims.n_audio_ctx
-    dec_bytes_per_step = 2.0 * (L * (10 * D * D + 8 * D * D) + V * D) + B * L * 2 * T * D * 2.0   # weights once + cross-KV of B clips
+    # weights touched once per step = per layer q|k|v|o (4 D^2) + cross q|o (2 D^2; cross k|v are applied once per clip by the
+    # encode call, not per step) + MLP (8 D^2) = 14 D^2, + the tied embedding V D; + the cross-KV of every clip
+    dec_bytes_per_step = 2.0 * (L * 14 * D * D + V * D) + B * L * 2 * T * D * 2.0
 
     def summarize(pf, passes):
         """roofline of the dominant kernel class (largest device time) + per-class figures, from HIP-event records of `passes` passes"""
@@ -401,7 +522,7 @@ def main():
         dec_gbs = dec_bytes_per_step * steps_d / (ms_d * 1e-3) / 1e9 if ms_d else 0.0
         tot = sum(v[1] for v in pf.values()) or 1.0
         if pf["enc_gemm"][1] >= pf["decode"][1]:
-            rl = {"kernel": "gemm_nt_kernel_256 (encoder Linear/Conv GEMMs, 256x256x64 MFMA tiles)", "bound": "mfma",
+            rl = {"kernel": "gemm_nt_kernel_8ph (encoder Linear/Conv GEMMs, 256x256x64 MFMA tiles)", "bound": "mfma",
                   "achieved": round(gemm_tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(gemm_tflops / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                   "launches": n_l, "avg_launch_ms": round(ms_l / max(n_l, 1), 4), "flop_per_launch_avg": w_l / max(n_l, 1)}
@@ -413,10 +534,11 @@ def main():
         # HBM traffic per launch from the committed PMC passes of this same workload (rocprofv3 cannot run inside the timed process):
         # profiles/r01_pmc_summary.json, made by tools/pmc_summary.py with the guide's gfx950 corrections.  null when absent.
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")))
+            pmc_name = next(n for n in ("r02_pmc_summary.json", "r01_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             rl["traffic"] = round(pmc["decode_step"]["hbm_bytes_per_step"] if rl["bound"] == "hbm" else pmc["encoder_gemm"]["hbm_bytes_per_launch"], 0)
-            rl["traffic_source"] = "profiles/r01_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
-        except (OSError, KeyError, ValueError):
+            rl["traffic_source"] = f"profiles/{pmc_name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         stg = {k: {"ms_per_pass": round(v[1] / passes, 3), "share_of_device_time": round(v[1] / tot, 4)} for k, v in pf.items()}
         stg["enc_gemm"]["tflops"] = round(gemm_tflops, 1)
@@ -428,9 +550,11 @@ def main():
         stg["decode"]["steps_per_pass"] = steps_d / max(n_d, 1)
         return rl, stg
 
-    roofline, stage = summarize(prof, args.steps if R == 1 else 1)
-    roofline["measured_over"] = ("the timed region" if R == 1 else
-                                 f"one uncontended calibration pass in this process (the timed region runs {R} concurrent streams, un-instrumented)")
+    roofline, stage = summarize(prof, args.steps if R == 1 else n_serial)
+    roofline["measured_over"] = ("the timed region (serial passes)" if R == 1 else
+                                 f"{n_serial} serial passes on one replica in this process, nothing else on the GPU (`execution`); the pipelined timed region of `value` runs {R} concurrent streams un-instrumented")
+    if serial_exec:
+        roofline["execution"] = serial_exec
     steps_d, n_d = prof["decode"][2], prof["decode"][0]
     if R > 1:      # device-level view of the timed region: algorithmic decode bytes of every pass over the wall time (encoders run in the same time)
         roofline["timed_region_decode_bytes_over_wall_GBs"] = round(dec_bytes_per_step * (steps_d / max(n_d, 1)) * args.steps / elapsed / 1e9, 1)
@@ -444,7 +568,7 @@ def main():
                                f"(T=0, timestamps, max_tokens 448, one window per clip), random-init N(0,0.02^2) weights",
                    "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "generated_tokens_per_clip_mean": float(n_gen.mean()), "decoder_steps_per_pass": steps_d / max(n_d, 1),
-                   "realtime_factor": round(value, 1), "replicas": R,
+                   "realtime_factor": round(value, 1), "replicas": R, "exchange": dp_mode,
                    "pipeline": (f"{R} model replicas (one weight copy, own activations / KV caches / step graphs) on {R} HIP streams, passes dealt round-robin: the encoder of one batch overlaps the decoder of "
                                 "another; every pass is a complete log-mel + encode + decode of its 32 clips" if R > 1 else "strictly serial passes")},
         "roofline": roofline, "stages": stage,
@@ -454,6 +578,11 @@ def main():
         out["codec"] = codec_bench(ctx, torch)
     if rank == 0 and args.lm:
         out["lm"] = lm_bench(ctx, torch, args.lm, args.lm_batch)
+    if rank == 0 and not args.no_config0 and not args.no_cpu_baseline:
+        try:
+            out["config0"] = config0_leg(ctx, torch)
+        except Exception as e:
+            out["config0"] = {"error": repr(e)}
     if rank == 0 and not args.no_cpu_baseline:
         try:
             ncpu = min(16, len(os.sched_getaffinity(0)))   # the GPU box's CPU share for one GPU is 16 cores
@@ -466,6 +595,8 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     for rp in reversed(reps):                     # clones before the replica that owns the weights
+        if rp.dp_abi:
+            P.dp_shutdown(rp.ctx)
         rp.model.close()
 
 

@@ -102,6 +102,27 @@ int mia_mel_s3gen(mia_ctx* ctx, const float* pcm, int64_t n_samples, float* mel,
 int64_t mia_resample_linear_len(int64_t n_samples, float scale);
 int mia_resample_linear(mia_ctx* ctx, const float* x, int64_t n_samples, float scale, float* out, int mem);
 
+/* ---- data-parallel exchange (SURVEY.md section 8b "multi-GPU", 8e) ------------------------------------------------- */
+/* Clips shard across the GPUs of one node (one process and one mia_ctx per GPU, full weight replica per rank); the path's only
+ * exchange is ONE all-gather of the int32 token rows per pass, over RCCL / xGMI, enqueued on the context's own stream.  The
+ * reference has no multi-device path (one actor, one Metal device: STT/Whisper/WhisperSTT.swift:11); these entry points are what
+ * a Swift host driving 8 processes would bind.
+ *   shard rule: contiguous shards, the first n_items % world ranks hold one item more (mia_dp_shard_range, host arithmetic);
+ *   mia_dp_unique_id: rank 0 makes the 128-byte RCCL id and hands it to the other ranks by its own means (pipe, file, env);
+ *   mia_dp_init: collective over all ranks (ncclCommInitRank); one communicator per context; mia_dp_shutdown destroys it
+ *     (mia_destroy does too);
+ *   mia_dp_gather_tokens: DEVICE pointers; local_tokens [b_local][L] + local_counts [b_local] of this rank ->
+ *     all_tokens [n_items][L] + all_counts [n_items] in global clip order on EVERY rank; stream-ordered, no host sync in steady state;
+ *   mia_dp_unpack_host: the unpadding step of the gather on host buffers (gathered [world][cap][L], cap = mia_dp_shard_cap). */
+int mia_dp_shard_range(int n_items, int rank, int world, int* lo, int* hi);
+int mia_dp_shard_cap(int n_items, int world);
+int mia_dp_unpack_host(const int32_t* gathered, int n_items, int world, int L, int32_t* dense);
+int mia_dp_unique_id(mia_ctx* ctx, void* id128);
+int mia_dp_init(mia_ctx* ctx, int rank, int world, const void* unique_id);
+int mia_dp_shutdown(mia_ctx* ctx);
+int mia_dp_gather_tokens(mia_ctx* ctx, const int32_t* local_tokens, const int32_t* local_counts, int b_local, int L, int n_items,
+                         int32_t* all_tokens, int32_t* all_counts);
+
 /* ---- operator level -------------------------------------------------------------------------- */
 /* y = act(x W^T + b) + r : the dense contraction behind every MLXNN Linear on the path
  * (e.g. STT/Whisper/Layers/MultiHeadAttention.swift:40-58,134; ResidualAttentionBlock.swift:91).

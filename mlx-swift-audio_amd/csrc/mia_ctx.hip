@@ -41,6 +41,7 @@ extern "C" void mia_destroy(mia_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)mia_dp_shutdown(ctx);
   for (auto& t : ctx->mel_tables) {
     (void)hipFree(t.window);
     (void)hipFree(t.twiddle);

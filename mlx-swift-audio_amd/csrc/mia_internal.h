@@ -36,6 +36,11 @@ struct mia_ctx {
   struct ProfRec { int cls; hipEvent_t start, stop; double work; };
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
+  // data-parallel exchange (dp.hip): one RCCL communicator per context, collectives run on the context's stream
+  void* dp_comm = nullptr;
+  int dp_rank = 0, dp_world = 0, dp_plan_items = -1;
+  void* dp_buf = nullptr;
+  size_t dp_buf_bytes = 0;
 };
 
 enum { MIA_PROF_LOGMEL = 0, MIA_PROF_ENC_GEMM = 1, MIA_PROF_ENC_ATTN = 2, MIA_PROF_ENC_NORM = 3, MIA_PROF_DECODE = 4,

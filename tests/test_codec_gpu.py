@@ -58,6 +58,40 @@ def test_dac_decode_matches_oracle(ctx):
     dec.close()
 
 
+def test_snac_24khz_real_geometry(ctx):
+    """mlx-community/snac_24khz shapes (768-d latent, 1024 -> 64 channels, rates 8.8.4.2, depthwise): ~1 s of audio vs the oracle.
+    The tolerance is the micro-model one scaled by the depth of the 1024-channel stack (fp32 both sides, different sum orders)."""
+    from mlx_swift_audio_amd import codec as HC
+    cfg = S.SNAC_CONFIGS["snac_24khz"]
+    w = S.snac_weights(cfg, seed=6)
+    dec = HC.SNACDecoder.load(ctx, cfg, w)
+    ora = OC.SNACOracle(cfg, w)
+    rng = np.random.default_rng(8)
+    n = 12                                                        # 12 frames -> 24 576 samples
+    codes = [rng.integers(0, cfg.codebook_size, n * (cfg.vq_strides[0] // s)).tolist() for s in cfg.vq_strides]
+    T0 = n * cfg.vq_strides[0]
+    noise = rng.standard_normal(dec.noise_len(T0)).astype(np.float32)
+    got, ref = dec.decode(codes, noise), ora.decode(codes, noise)
+    assert got.shape == ref.shape == (T0 * int(np.prod(cfg.decoder_rates)),)
+    assert np.abs(got - ref).max() <= 5e-4, np.abs(got - ref).max()
+    dec.close()
+
+
+def test_dac_speech_real_geometry(ctx):
+    """The DAC speech configuration (1536 -> 96 channels, rates 8.5.4.2, 2 x 1024 codebooks): 60 code steps vs the oracle."""
+    from mlx_swift_audio_amd import codec as HC
+    cfg = S.DAC_CONFIGS["dac_speech"]
+    w = S.dac_weights(cfg, seed=7)
+    dec = HC.DACCodec.load(ctx, cfg, w)
+    ora = OC.DACOracle(cfg, w)
+    codes = np.random.default_rng(2).integers(0, cfg.codebook_size, (1, cfg.n_codebooks, 60))
+    got = dec.decode_from_codes(codes)
+    ref = ora.decode_from_codes(codes[0])
+    assert got[0].shape == ref.shape
+    assert np.abs(got[0] - ref).max() <= 5e-4, np.abs(got[0] - ref).max()
+    dec.close()
+
+
 def test_codec_error_paths(ctx):
     import mlx_swift_audio_amd as m
     from mlx_swift_audio_amd import codec as HC

@@ -116,3 +116,100 @@ def test_qwen2_half_billion_full_size(ctx):
     assert np.abs(stepped - ref).max() <= 0.08 * ref.std()
     assert np.abs(got - stepped).max() <= 0.05 * ref.std()           # two fp32 summation orders in front of the same 16-bit roundings, 24 layers deep
     model.close()
+
+
+def test_orpheus_3b_shape_two_layers(ctx):
+    """Orpheus-3B geometry (d 3072, 24:8 GQA heads of 128, FFN 8192, V 156 940, Llama-3 RoPE scaling) at reduced depth (2 of 28
+    layers): last-position logits of a 24-token prompt (batched prompt pass + one step) vs the fp32 oracle, stepping vs prompt pass,
+    and a short sampled continuation checked token by token under the boundary rule."""
+    import dataclasses
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    from oracle import lm as OLM
+    cfg = dataclasses.replace(S.LM_CONFIGS["orpheus-3b"], n_layers=2)
+    w = S.lm_weights(cfg, seed=1, round_to="bf16")
+    model = HL.CausalLM.load(ctx, cfg, w, m.BF16)
+    ora = OLM.LMOracle(cfg, w)
+    ids = np.random.default_rng(1).integers(0, cfg.vocab, 24).tolist()
+    got = model.forward(ids)
+    ref = ora.forward(ids).numpy()[-1]
+    assert got.shape == ref.shape == (cfg.vocab,)
+    assert np.abs(got - ref).max() <= 0.08 * ref.std(), (np.abs(got - ref).max(), ref.std())
+    model.reset()
+    for t in ids[:-1]:
+        model.forward([t])
+    stepped = model.forward([ids[-1]])
+    assert np.abs(stepped - ref).max() <= 0.08 * ref.std()
+    n_new = 10
+    u = np.random.default_rng(2).random(n_new).astype(np.float32)
+    kw = {"temperature": 0.6, "top_p": 0.8, "rep_penalty": 1.3, "rep_window": 20, "max_new_tokens": n_new, "stop_ids": (128258,)}
+    gen = model.generate(ids, u, temperature=0.6, top_p=0.8, rep_penalty=1.3, rep_window=20, max_new_tokens=n_new, stop_ids=(128258,))
+    trace = []
+    want = OLM.generate(ora, ids, kw, u, trace)
+    k = next((i for i, (a, b) in enumerate(zip(gen, want)) if a != b), min(len(gen), len(want)))
+    if not (k == len(gen) == len(want)):
+        assert min(trace[k]) < 2e-2, (k, trace[k], gen, want)       # bf16: the CDF moves by ~max|logit error| / T
+    model.close()
+
+
+def test_whisper_large_v3_decoder_eight_layers(ctx):
+    """large-v3's decoder geometry (the per-GPU shape of BASELINE configs[4]) at reduced depth: 2 encoder + 8 of 32 decoder layers at
+    full width (d 1280, 20 heads, V 51 866), 2 clips, 24 tokens vs the oracle under the margin rule -- covers the decoder layer loop
+    beyond turbo's 4 layers (cross-KV layer strides, step graph with 90 nodes)."""
+    import dataclasses
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import whisper as HW
+    from oracle import logmel as OL
+    from oracle import whisper as OW
+    dims = dataclasses.replace(S.DIMS["large-v3"], n_audio_layer=2, n_text_layer=8)
+    weights = S.synthetic_weights(dims, seed=3, style="survey", round_to="bf16")
+    model = HW.WhisperModel.load(ctx, dims, weights, m.BF16)
+    n_new = 24
+    o = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(model.special), blank_ids=[220], max_new_tokens=n_new)
+    clips = [S.synth_clip(40), S.synth_clip(41)]
+    got = model.transcribe_windows(clips, o)
+    feats = model.audio_features()
+    ora = OW.WhisperOracle(dims, weights)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    oo = OW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=n_new)
+    for b in range(2):
+        mel = OW.round_array(OL.whisper_log_mel_spectrogram(clips[b], dims.n_mels, padding=OL.N_SAMPLES)[:OL.N_FRAMES], "bf16")[None]
+        xa = ora.encode(mel)
+        scale = np.abs(xa.numpy()).max()
+        assert np.abs(feats[b] - xa.numpy()[0]).max() <= 0.03 * scale
+        ref = OW.greedy_decode(ora, st, xa, oo)
+        k = next((i for i, (a, c) in enumerate(zip(got[b].tokens, ref.tokens)) if a != c), min(len(got[b].tokens), len(ref.tokens)))
+        # (random-init logits are nearly flat: top-2 margins of a few 1e-2 are common, so a fork may come early; it is legal only
+        # where the ORACLE's own margin is inside the bf16 noise of 8 decoder layers, and never on the first, rule-forced token)
+        assert k == len(ref.tokens) or ref.margins[k] < 0.05, (b, k, ref.margins[k], got[b].tokens[:k + 2], ref.tokens[:k + 2])
+        assert k >= 1, (b, k, got[b].tokens, ref.tokens)
+        np.testing.assert_allclose(got[b].no_speech_prob, ref.no_speech_prob, rtol=0.1, atol=1e-6)
+    model.close()
+
+
+def test_whisper_tiny_en_config0(ctx):
+    """BASELINE configs[0]: Whisper tiny.en (80 mels, d 384, 6 heads, 4 + 4 layers, V 51 864, SOT sequence [sot]), greedy transcribe of
+    one 10 s mono clip -- the whole model at its real size, f16 parity mode, vs the oracle (features, every token, avg_logprob)."""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import whisper as HW
+    from oracle import logmel as OL
+    from oracle import whisper as OW
+    dims = S.DIMS["tiny.en"]
+    weights = S.synthetic_weights(dims, seed=2, style="survey", round_to="f16")
+    model = HW.WhisperModel.load(ctx, dims, weights, m.F16)
+    n_new = 48
+    o = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(model.special), blank_ids=[220], max_new_tokens=n_new)
+    clip = S.synth_clip(0)[:160000]                                    # 10 s
+    got = model.transcribe_windows([clip], o)[0]
+    feats = model.audio_features()[0]
+    ora = OW.WhisperOracle(dims, weights)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    assert st.sot_sequence(0, "transcribe") == [st.sot]                  # English-only: WhisperTokenizer.swift:382-384
+    mel = OW.round_array(OL.whisper_log_mel_spectrogram(clip, dims.n_mels, padding=OL.N_SAMPLES)[:OL.N_FRAMES], "f16")[None]
+    xa = ora.encode(mel)
+    assert np.abs(feats - xa.numpy()[0]).max() <= 0.01 * max(1.0, np.abs(xa.numpy()).max())
+    ref = OW.greedy_decode(ora, st, xa, OW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=n_new))
+    k = next((i for i, (a, c) in enumerate(zip(got.tokens, ref.tokens)) if a != c), min(len(got.tokens), len(ref.tokens)))
+    assert k == len(ref.tokens) or ref.margins[k] < 0.03, (k, ref.margins[k], got.tokens, ref.tokens)
+    assert k >= 8
+    model.close()

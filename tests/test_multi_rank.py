@@ -72,3 +72,58 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         P.shard_range(4, 2, 2)
+
+
+def test_abi_shard_and_unpack_match_python_rule():
+    """The C-ABI side of the exchange (mia_dp_shard_range / mia_dp_shard_cap / mia_dp_unpack_host: host arithmetic, no GPU): same
+    shard rule as parallel.shard_range, and unpadding of a simulated all-gather image [world][cap][L] restores global clip order
+    for even, ragged, tiny and empty shard sets."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import parallel as P
+    lib = m._lib.load()
+    lib.mia_dp_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mia_dp_unpack_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L = 7
+    for n in (0, 1, 5, 32, 256, 257):
+        for w in (1, 2, 3, 8):
+            cap = lib.mia_dp_shard_cap(n, w)
+            assert cap == -(-n // w)
+            gathered = np.full((w, max(cap, 1), L), -1, np.int32)      # what ncclAllGather leaves: every rank's padded shard
+            for r in range(w):
+                lo, hi = C.c_int(), C.c_int()
+                assert lib.mia_dp_shard_range(n, r, w, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == P.shard_range(n, r, w)
+                toks, _ = _fake_tokens(lo.value, hi.value, L)
+                gathered[r, :hi.value - lo.value] = toks.numpy()
+            dense = np.zeros((max(n, 1), L), np.int32)
+            g = np.ascontiguousarray(gathered[:, :cap]) if cap else gathered
+            assert lib.mia_dp_unpack_host(g.ctypes.data, n, w, L, dense.ctypes.data) == 0
+            np.testing.assert_array_equal(dense[:n], _fake_tokens(0, n, L)[0].numpy())
+    assert lib.mia_dp_shard_range(4, 2, 2, None, None) != 0          # rank out of range / null outputs are rejected
+    assert lib.mia_dp_shard_cap(4, 0) < 0
+
+
+@pytest.mark.gpu
+def test_abi_rccl_gather_world_1(ctx):
+    """mia_dp_* on the real RCCL (one rank: communicator set-up, the all-gather on the context's stream, unpadding, shutdown)."""
+    import numpy as np
+    from mlx_swift_audio_amd import parallel as P
+    uid = P.dp_unique_id(ctx)
+    assert len(uid) == 128
+    P.dp_init(ctx, 0, 1, uid)
+    toks, counts = _fake_tokens(0, 5, 16)
+    t_d, c_d = toks.cuda(), counts.cuda()
+    out_t, out_c = torch.zeros_like(t_d), torch.zeros_like(c_d)
+    for _ in range(3):                                                # the plan is cached after the first call
+        P.dp_gather_tokens(ctx, t_d.data_ptr(), c_d.data_ptr(), 5, 16, 5, out_t.data_ptr(), out_c.data_ptr())
+    ctx.synchronize()
+    assert torch.equal(out_t.cpu(), toks) and torch.equal(out_c.cpu(), counts)
+    import mlx_swift_audio_amd as m
+    with pytest.raises(m.MiaError):
+        P.dp_gather_tokens(ctx, t_d.data_ptr(), c_d.data_ptr(), 4, 16, 5, out_t.data_ptr(), out_c.data_ptr())   # wrong shard size
+    P.dp_shutdown(ctx)
+    with pytest.raises(m.MiaError):
+        P.dp_gather_tokens(ctx, t_d.data_ptr(), c_d.data_ptr(), 5, 16, 5, out_t.data_ptr(), out_c.data_ptr())   # no communicator
