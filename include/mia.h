@@ -42,7 +42,7 @@ typedef enum {
   MIA_ERR_UNSUPPORTED = -6
 } mia_status;
 
-typedef enum { MIA_F32 = 0, MIA_F16 = 1, MIA_BF16 = 2 } mia_dtype;
+typedef enum { MIA_F32 = 0, MIA_F16 = 1, MIA_BF16 = 2, MIA_U32 = 3 /* packed quantisation codes */ } mia_dtype;
 typedef enum { MIA_MEM_HOST = 0, MIA_MEM_DEVICE = 1 } mia_mem;
 
 /* ---- context -------------------------------------------------------------------------------- */
@@ -288,6 +288,20 @@ int mia_snac_decode(mia_codec* c, const int32_t* const* codes, const int32_t* n_
 /* Replaces DACCodec.decodeFromCodes (Codec/DAC/DACModel.swift:303-306) for one sequence: codes int32 [n_codebooks][T]. */
 int mia_dac_decode(mia_codec* c, const int32_t* codes, int n_codebooks, int64_t T, float* pcm, int64_t pcm_capacity,
                    int64_t* n_samples, int mem);
+/* Encoder side of the DAC codec: replaces DACCodec.encode (Codec/DAC/DACModel.swift:284-296): preprocess (right-pad to the hop
+ * length :308-317) -> DACEncoder (:43-86; blocks :15-38) -> residual vector quantisation (DACQuantize.swift:147-190, nearest entry
+ * on L2-normalised vectors :87-115, first index on ties).  mia_dac_load_encoder attaches the `encoder.*` and
+ * `quantizer.quantizers.N.in_proj.*` tensors to a handle made by mia_dac_load (encoder_dim * 2^n_rates must equal its latent width).
+ * mia_dac_encode: pcm float32 mono [n_samples] -> codes int32 [n_quantizers][codes_capacity] (row q holds *n_steps ids);
+ * n_quantizers <= 0 = all codebooks.  mia_dac_code_len(n_samples) = steps produced. */
+typedef struct {
+  int32_t encoder_dim;
+  int32_t n_rates; int32_t encoder_rates[8];
+} mia_dac_encoder_config;
+int mia_dac_load_encoder(mia_codec* c, const mia_dac_encoder_config* cfg, const mia_tensor_view* tensors, int n_tensors);
+int64_t mia_dac_code_len(mia_codec* c, int64_t n_samples);
+int mia_dac_encode(mia_codec* c, const float* pcm, int64_t n_samples, int n_quantizers, int32_t* codes, int64_t codes_capacity,
+                   int64_t* n_steps, int mem);
 
 /* ---- autoregressive LMs (Llama-3 / Qwen2 blocks) ------------------------------------------------ */
 /* OrpheusConfig (TTS/Orpheus/BuildingBlocks/TransformerBlock.swift:16-34) / Qwen2Config (TTS/CosyVoice2/LLM/Qwen2LM.swift:15-43).
@@ -313,6 +327,14 @@ typedef struct {
 } mia_lm_sampler;
 
 mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia_tensor_view* tensors, int n_tensors, int dtype);
+/* MLX-affine 4-bit (group 64) weights for the decode step: the reference's default Orpheus / CosyVoice2 checkpoints are quantised
+ * (TTS/Orpheus/TTSEngine/OrpheusWeightLoader.swift:28-60) and MLX multiplies them packed (quantizedMatmul).  mia_lm_attach_q4 takes
+ * every step Linear as stored -- `<name>.weight` (MIA_U32 codes [N][K/8], 8 per word, little end first), `<name>.scales`, `<name>.biases`
+ * ([N][K/64], both f16 or both bf16) -- onto a handle loaded from the de-quantised checkpoint; the per-token step then streams 4.5 bits
+ * per weight and expands them in registers to exactly the 16-bit values of the expanded checkpoint (identical logits), the batched
+ * prompt pass keeps the 16-bit copy.  mia_lm_use_q4 toggles the step between the two (0 = 16-bit). */
+int mia_lm_attach_q4(mia_lm* lm, const mia_tensor_view* tensors, int n_tensors, int group_size);
+int mia_lm_use_q4(mia_lm* lm, int on);
 void mia_lm_free(mia_lm* lm);
 int mia_lm_reset(mia_lm* lm);
 /* model(ids, cache) then logits[0,-1] (OrpheusTTS.swift:245-251,289): appends n ids to the KV cache, returns the fp32

@@ -22,10 +22,20 @@ class _DacCfg(C.Structure):
                 ("n_codebooks", C.c_int32), ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32)]
 
 
+class _DacEncCfg(C.Structure):
+    _fields_ = [("encoder_dim", C.c_int32), ("n_rates", C.c_int32), ("encoder_rates", C.c_int32 * 8)]
+
+
 def _declare(lib):
     if getattr(lib, "_codec_declared", False):
         return
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.mia_dac_load_encoder.restype = i32
+    lib.mia_dac_load_encoder.argtypes = [vp, C.POINTER(_DacEncCfg), C.POINTER(_TensorView), i32]
+    lib.mia_dac_code_len.restype = i64
+    lib.mia_dac_code_len.argtypes = [vp, i64]
+    lib.mia_dac_encode.restype = i32
+    lib.mia_dac_encode.argtypes = [vp, vp, i64, i32, vp, i64, C.POINTER(i64), i32]
     lib.mia_snac_load.restype = vp
     lib.mia_snac_load.argtypes = [vp, C.POINTER(_SnacCfg), C.POINTER(_TensorView), i32]
     lib.mia_dac_load.restype = vp
@@ -113,7 +123,21 @@ class DACCodec(_Codec):
         h = ctx.lib.mia_dac_load(ctx.h, C.byref(c), views, len(weights))
         if not h:
             raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, ctx.lib.mia_last_error(ctx.h).decode())
-        return DACCodec(ctx, h, cfg)
+        codec = DACCodec(ctx, h, cfg)
+        if "encoder.block.layers.0.weight_v" in weights:            # checkpoints carry the encoder; decode-only callers may drop it
+            e = _DacEncCfg(cfg.encoder_dim, len(cfg.encoder_rates), (C.c_int32 * 8)(*cfg.encoder_rates))
+            ctx.check(ctx.lib.mia_dac_load_encoder(h, C.byref(e), views, len(weights)))
+        return codec
+
+    def encode(self, audio: np.ndarray, n_quantizers: int | None = None) -> np.ndarray:
+        """DACCodec.encode(_:nQuantizers:) for one mono sequence (DACModel.swift:284-296): float32 [samples] -> codes int32 [n_q, T]."""
+        a = np.ascontiguousarray(audio, np.float32).reshape(-1)
+        T = int(self.ctx.lib.mia_dac_code_len(self.h, a.size))
+        nq = self.cfg.n_codebooks if not n_quantizers else min(n_quantizers, self.cfg.n_codebooks)
+        codes = np.zeros((nq, max(T, 1)), np.int32)
+        ns = C.c_int64(0)
+        self.ctx.check(self.ctx.lib.mia_dac_encode(self.h, a.ctypes.data, a.size, nq, codes.ctypes.data, codes.shape[1], C.byref(ns), _lib.MEM_HOST))
+        return codes[:, :ns.value]
 
     def decode_from_codes(self, codes: np.ndarray) -> np.ndarray:
         """decodeFromCodes: codes int [B, n_codebooks, T] (or [n_codebooks, T]) -> float32 [B, samples] (or [samples])."""

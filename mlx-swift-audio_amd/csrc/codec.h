@@ -46,3 +46,6 @@ int codec_dwconv_launch(const float* x, float* y, const float* w, const float* b
 int codec_conv_out1_launch(const float* x, float* out, const float* w, const float* bias, const float* alpha, int T, int C, int K, hipStream_t s);
 int codec_embed_launch(const EmbedArgs& a, float* z, int T, int C, hipStream_t s);
 int codec_noise1_launch(float* x, const float* w, const float* noise, int T, int C, hipStream_t s);
+int codec_conv_in1_launch(const float* x, float* y, const float* w, const float* bias, int64_t T, int C, int K, int pad, hipStream_t s);
+int codec_vq_assign_launch(const float* zE, const float* cbn, const float* cbn_sq, const float* cb, const float* weff, const float* bias,
+                           float* residual, int32_t* codes, int T, int C, int cs, int cd, hipStream_t s);

@@ -45,6 +45,16 @@ struct mia_codec {
   int32_t* d_codes = nullptr; size_t codes_cap = 0;
   float* d_noise = nullptr; size_t noise_cap = 0;
   float* d_pcm = nullptr; size_t pcm_cap = 0;
+  // ---- encoder side (mia_dac_load_encoder): conv_in1 -> [3 residual units, snake + strided conv] x n -> snake + conv3, then the RVQ stages
+  bool has_encoder = false;
+  int enc_dim = 0, hop = 1;
+  float* enc_in_w = nullptr; float* enc_in_b = nullptr;    // first conv [C][7], [C]
+  std::vector<Op> enc_ops;
+  Op in_proj[MIA_MAX_LEVELS];
+  float* cbn[MIA_MAX_LEVELS] = {};                         // L2-normalised codebooks + their squared norms
+  float* cbn_sq[MIA_MAX_LEVELS] = {};
+  float* d_audio = nullptr; size_t audio_cap = 0;
+  float* d_ze = nullptr; size_t ze_cap = 0;
 };
 
 namespace {
@@ -295,6 +305,8 @@ extern "C" void mia_codec_free(mia_codec* c) {
   if (c->d_codes) (void)hipFree(c->d_codes);
   if (c->d_noise) (void)hipFree(c->d_noise);
   if (c->d_pcm) (void)hipFree(c->d_pcm);
+  if (c->d_audio) (void)hipFree(c->d_audio);
+  if (c->d_ze) (void)hipFree(c->d_ze);
   delete c;
 }
 
@@ -504,4 +516,135 @@ extern "C" int mia_dac_decode(mia_codec* c, const int32_t* codes, int n_codebook
   }
   MIA_CHECK_ARG(ctx, pcm_capacity >= mia_codec_output_len(c, T), "dac_decode: pcm buffer too small");
   return decode_common(c, ea, T, nullptr, 0, pcm, n_samples, mem);
+}
+
+
+// ---- DAC encoder + residual vector quantisation (Codec/DAC/DACModel.swift:13-86,284-296; DACQuantize.swift:54-116,147-190) -------------------
+extern "C" int mia_dac_load_encoder(mia_codec* c, const mia_dac_encoder_config* cfg, const mia_tensor_view* tensors, int n_tensors) {
+  if (!c) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = c->ctx;
+  MIA_CHECK_ARG(ctx, c->kind == 1, "dac_load_encoder: handle is not a DAC model");
+  MIA_CHECK_ARG(ctx, cfg && tensors && n_tensors > 0 && cfg->n_rates > 0 && cfg->n_rates <= 8, "dac_load_encoder: bad arguments");
+  MIA_CHECK_ARG(ctx, cfg->encoder_dim % 32 == 0 && (cfg->encoder_dim << cfg->n_rates) == c->latent,
+                "dac_load_encoder: encoder_dim * 2^n_rates (%d) must equal the latent width (%d) and be a multiple of 32", cfg->encoder_dim << cfg->n_rates, c->latent);
+  MIA_CHECK_ARG(ctx, !c->has_encoder, "dac_load_encoder: encoder already loaded");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  Loader L; L.c = c;
+  for (int i = 0; i < n_tensors; ++i) if (tensors[i].name && tensors[i].data) L.by_name[tensors[i].name] = &tensors[i];
+  const std::string E = "encoder.block.layers.";
+  int C = cfg->encoder_dim;
+  {  // first conv: 1 -> C channels, k7
+    std::vector<float> v, g, b;
+    if (L.f32(E + "0.weight_v", v, {C, 7, 1}) && L.f32(E + "0.weight_g", g, {C, 1, 1}) && L.f32(E + "0.bias", b, {C})) {
+      Loader::fold_wn(v, g, C, 7, 1, 0);
+      c->enc_in_w = L.up(v); c->enc_in_b = L.up(b);
+    }
+  }
+  c->hop = 1;
+  const int dils[3] = {1, 3, 9};
+  for (int i = 0; i < cfg->n_rates && L.err.empty(); ++i) {
+    const int st = cfg->encoder_rates[i];
+    MIA_CHECK_ARG(ctx, st >= 1, "dac_load_encoder: bad stride");
+    const std::string b = E + std::to_string(1 + i) + ".block.layers.";
+    for (int r = 0; r < 3; ++r) add_residual_unit_dac(L, b + std::to_string(r), C, dils[r], c->enc_ops);
+    Op dn; dn.kind = OP_CONV; dn.stride = st; dn.pad = (st + 1) / 2;
+    dn.a_pre = L.alpha(b + "3.alpha", C, false);
+    L.dense_conv(b + "4", 2 * C, 2 * st, C, true, dn);
+    c->enc_ops.push_back(dn);
+    C *= 2; c->hop *= st;
+  }
+  {
+    Op fin; fin.kind = OP_CONV; fin.pad = 1;
+    fin.a_pre = L.alpha(E + std::to_string(1 + cfg->n_rates) + ".alpha", C, false);
+    L.dense_conv(E + std::to_string(2 + cfg->n_rates), c->latent, 3, C, true, fin);
+    c->enc_ops.push_back(fin);
+  }
+  for (int i = 0; i < c->n_levels && L.err.empty(); ++i) {
+    const std::string q = "quantizer.quantizers." + std::to_string(i);
+    c->in_proj[i].kind = OP_CONV;
+    L.dense_conv(q + ".in_proj", c->cb_dim, 1, c->latent, true, c->in_proj[i]);
+    std::vector<float> cb;
+    if (!L.f32(q + ".codebook.weight", cb, {c->cb_size, c->cb_dim})) break;
+    std::vector<float> sq(c->cb_size);
+    for (int j = 0; j < c->cb_size; ++j) {      // l2Normalize (DACQuantize.swift:14-20) in float32, then the row's squared norm
+      float ss = 0.f;
+      for (int d = 0; d < c->cb_dim; ++d) { const float a = std::fabs(cb[(size_t)j * c->cb_dim + d]); ss += a * a; }
+      const float nrm = std::max(std::sqrt(ss), 1e-12f);
+      float s2 = 0.f;
+      for (int d = 0; d < c->cb_dim; ++d) { float& x = cb[(size_t)j * c->cb_dim + d]; x = x / nrm; s2 += x * x; }
+      sq[j] = s2;
+    }
+    c->cbn[i] = L.up(cb); c->cbn_sq[i] = L.up(sq);
+  }
+  if (!L.err.empty()) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "dac_load_encoder: %s", L.err.c_str());
+  MIA_HIP(ctx, hipDeviceSynchronize());
+  c->enc_dim = cfg->encoder_dim;
+  c->has_encoder = true;
+  return MIA_OK;
+}
+
+extern "C" int64_t mia_dac_code_len(mia_codec* c, int64_t n_samples) {
+  if (!c || !c->has_encoder || n_samples <= 0) return 0;
+  int64_t T = (n_samples + c->hop - 1) / c->hop * c->hop;
+  for (const Op& op : c->enc_ops) if (op.kind == OP_CONV && op.stride > 1) T = (T + 2 * op.pad - op.taps) / op.stride + 1;
+  return T;
+}
+
+extern "C" int mia_dac_encode(mia_codec* c, const float* pcm, int64_t n_samples, int n_quantizers, int32_t* codes, int64_t codes_capacity,
+                              int64_t* n_steps, int mem) {
+  if (!c) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = c->ctx;
+  MIA_CHECK_ARG(ctx, c->kind == 1 && c->has_encoder, "dac_encode: no encoder loaded (mia_dac_load_encoder)");
+  MIA_CHECK_ARG(ctx, pcm && codes && n_samples > 0, "dac_encode: null pointer or empty audio");
+  MIA_CHECK_ARG(ctx, mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE, "dac_encode: bad mem");
+  const int nq = n_quantizers <= 0 ? c->n_levels : std::min(n_quantizers, c->n_levels);
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int64_t T0 = (n_samples + c->hop - 1) / c->hop * c->hop;          // preprocess: right-pad to the hop length (DACModel.swift:308-317)
+  const int64_t Tc = mia_dac_code_len(c, n_samples);
+  MIA_CHECK_ARG(ctx, Tc > 0 && codes_capacity >= Tc, "dac_encode: codes buffer too small (%lld < %lld steps)", (long long)codes_capacity, (long long)Tc);
+  MIA_CHECK_ARG(ctx, T0 < (1ll << 30), "dac_encode: audio too long for one call");
+  // widest activation: the first stage, T0 x encoder_dim (every later stage halves T*C or keeps it)
+  size_t max_floats = (size_t)T0 * c->enc_dim;
+  { int64_t T = T0; int C = c->enc_dim;
+    for (const Op& op : c->enc_ops) if (op.kind == OP_CONV && !op.residual && op.stride != -1) { if (op.stride > 1) T = (T + 2 * op.pad - op.taps) / op.stride + 1; C = op.N; max_floats = std::max(max_floats, (size_t)T * C); } }
+  int rc = ensure(c, max_floats);
+  if (rc != MIA_OK) return rc;
+  if ((rc = ensure_buf(c, c->d_audio, c->audio_cap, (size_t)T0)) != MIA_OK) return rc;
+  if ((rc = ensure_buf(c, c->d_ze, c->ze_cap, (size_t)Tc * 16)) != MIA_OK) return rc;
+  if ((rc = ensure_buf(c, c->d_codes, c->codes_cap, (size_t)nq * Tc)) != MIA_OK) return rc;
+  MIA_HIP(ctx, hipMemsetAsync(c->d_audio, 0, (size_t)T0 * 4, s));
+  MIA_HIP(ctx, hipMemcpyAsync(c->d_audio, pcm, (size_t)n_samples * 4, mem == MIA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+  float* x = c->buf[0]; float* h = c->buf[1]; float* y = c->buf[2];
+  int64_t T = T0; int C = c->enc_dim;
+  if (codec_conv_in1_launch(c->d_audio, x, c->enc_in_w, c->enc_in_b, T, C, 7, 3, s)) return mia_fail(ctx, MIA_ERR_DEVICE, "dac_encode: input conv launch failed");
+  for (const Op& op : c->enc_ops) {
+    const bool side = op.stride == -1;
+    const int st = op.stride > 1 ? op.stride : 1;
+    const int64_t T_out = st > 1 ? (T + 2 * op.pad - op.taps) / st + 1 : T;
+    ConvGemmArgs g;
+    g.X = op.residual ? h : x; g.ldx = op.Cin; g.T_in = (int)T; g.W = op.w; g.bias = op.b; g.alpha = op.a_pre;
+    g.M = (int)T_out; g.N = op.N; g.Cin = op.Cin; g.taps = op.taps; g.dil = op.dil; g.pad = op.pad; g.T_out = (int)T_out; g.x_row_mul = st;
+    if (op.residual) { g.R = x; g.ldr = op.N; g.Y = x; g.ldy = op.N; }
+    else { g.Y = side ? h : y; g.ldy = op.N; }
+    if (const char* e = codec_conv_gemm_check(g)) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
+    if (codec_conv_gemm_launch(g, 1, s)) return mia_fail(ctx, MIA_ERR_DEVICE, "dac_encode: conv launch failed");
+    if (!op.residual && !side) { std::swap(x, y); C = op.N; T = T_out; }
+  }
+  // residual vector quantisation: x holds z [Tc][latent] and becomes the residual
+  for (int i = 0; i < nq; ++i) {
+    const Op& ip = c->in_proj[i];
+    ConvGemmArgs g;
+    g.X = x; g.ldx = c->latent; g.T_in = (int)T; g.W = ip.w; g.bias = ip.b; g.M = (int)T; g.N = c->cb_dim; g.Cin = c->latent; g.T_out = (int)T;
+    g.Y = c->d_ze; g.ldy = c->cb_dim;
+    if (const char* e = codec_conv_gemm_check(g)) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "%s", e);
+    if (codec_conv_gemm_launch(g, 1, s)) return mia_fail(ctx, MIA_ERR_DEVICE, "dac_encode: in_proj launch failed");
+    if (codec_vq_assign_launch(c->d_ze, c->cbn[i], c->cbn_sq[i], c->codebook[i], c->weff[i], c->ebias[i], x, c->d_codes + (size_t)i * T, (int)T, c->latent,
+                               c->cb_size, c->cb_dim, s)) return mia_fail(ctx, MIA_ERR_DEVICE, "dac_encode: vq launch failed");
+  }
+  if (n_steps) *n_steps = T;
+  // codes [nq][T] -> caller's [nq][codes_capacity] rows
+  MIA_HIP(ctx, hipMemcpy2DAsync(codes, (size_t)codes_capacity * 4, c->d_codes, (size_t)T * 4, (size_t)T * 4, nq, mem == MIA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+  if (mem == MIA_MEM_HOST) MIA_HIP(ctx, hipStreamSynchronize(s));
+  return MIA_OK;
 }

@@ -294,6 +294,84 @@ __global__ __launch_bounds__(256) void noise_mod1(float* __restrict__ x, const f
   for (int c = lane; c < C; c += 64) xr[c] += s;
 }
 
+// ---- DAC encoder front: y[t][c] = b[c] + sum_k w[c][k] x[t + k - pad]   (Cin = 1 -> C channels; HBM-bound: one write of T x C floats)
+__global__ __launch_bounds__(256) void conv_in1(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
+                                                int64_t T, int C, int K, int pad) {
+  const int64_t total = T * (C / 4);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t t = e / (C / 4);
+    const int c = (int)(e - t * (C / 4)) * 4;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const int64_t xi = t + k - pad;
+        acc += w[(c + j) * K + k] * ((xi >= 0 && xi < T) ? x[xi] : 0.f);
+      }
+      o[j] = acc + bias[c + j];
+    }
+    *reinterpret_cast<float4*>(y + t * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---- one residual-VQ stage per time step (DACQuantize.swift:87-115,147-190): nearest codebook entry of the L2-normalised in_proj output
+// (first index wins ties, like argMax(-dist)), then residual[t][:] -= out_proj(zE + (codebook[idx] - zE)).
+struct VqArgs {
+  const float* zE;       // [T][cd]   in_proj output of this stage
+  const float* cbn;      // [cs][cd]  L2-normalised codebook (host, same formula as l2Normalize)
+  const float* cbn_sq;   // [cs]      sum of squares of the normalised rows
+  const float* cb;       // [cs][cd]  raw codebook
+  const float* weff;     // [C][cd]   folded out_proj
+  const float* bias;     // [C]
+  float* residual;       // [T][C]
+  int32_t* codes;        // [T]
+  int T, C, cs, cd;
+};
+__global__ __launch_bounds__(256) void vq_assign(VqArgs a) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  __shared__ float s_e[16], s_en[16], s_z[16];
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < a.cd) s_e[tid] = a.zE[(int64_t)t * a.cd + tid];
+  __syncthreads();
+  if (tid == 0) {     // l2Normalize: x / max(sqrt(sum |x|^2), 1e-12)
+    float ss = 0.f;
+    for (int d = 0; d < a.cd; ++d) ss += fabsf(s_e[d]) * fabsf(s_e[d]);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    float sq = 0.f;
+    for (int d = 0; d < a.cd; ++d) { s_en[d] = s_e[d] / nrm; sq += s_en[d] * s_en[d]; }
+    s_en[a.cd] = sq;
+  }
+  __syncthreads();
+  const float se = s_en[a.cd];
+  float best = INFINITY; int bi = 0x7fffffff;
+  for (int j = tid; j < a.cs; j += 256) {
+    float dot = 0.f;
+    for (int d = 0; d < a.cd; ++d) dot += s_en[d] * a.cbn[(int64_t)j * a.cd + d];
+    const float dist = (se - 2.0f * dot) + a.cbn_sq[j];
+    if (dist < best) { best = dist; bi = j; }         // ascending j per thread: the first minimum is kept
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { s_v[wave] = best; s_i[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w2 = 1; w2 < 4; ++w2) if (s_v[w2] < best || (s_v[w2] == best && s_i[w2] < bi)) { best = s_v[w2]; bi = s_i[w2]; }
+    a.codes[t] = bi;
+    for (int d = 0; d < a.cd; ++d) s_z[d] = s_e[d] + (a.cb[(int64_t)bi * a.cd + d] - s_e[d]);   // straight-through form (:62)
+  }
+  __syncthreads();
+  for (int c = tid; c < a.C; c += 256) {
+    float acc = 0.f;
+    for (int d = 0; d < a.cd; ++d) acc += s_z[d] * a.weff[(int64_t)c * a.cd + d];
+    a.residual[(int64_t)t * a.C + c] -= acc + a.bias[c];
+  }
+}
+
 }  // namespace
 
 const char* codec_conv_gemm_check(const ConvGemmArgs& g) {
@@ -348,5 +426,21 @@ int codec_embed_launch(const EmbedArgs& a, float* z, int T, int C, hipStream_t s
 
 int codec_noise1_launch(float* x, const float* w, const float* noise, int T, int C, hipStream_t s) {
   hipLaunchKernelGGL(noise_mod1, dim3((T + 3) / 4), dim3(256), 0, s, x, w, noise, T, C);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int codec_conv_in1_launch(const float* x, float* y, const float* w, const float* bias, int64_t T, int C, int K, int pad, hipStream_t s) {
+  if (C % 4) return -1;
+  const int64_t total = T * (C / 4);
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(conv_in1, dim3(grid), dim3(256), 0, s, x, y, w, bias, T, C, K, pad);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int codec_vq_assign_launch(const float* zE, const float* cbn, const float* cbn_sq, const float* cb, const float* weff, const float* bias,
+                           float* residual, int32_t* codes, int T, int C, int cs, int cd, hipStream_t s) {
+  if (cd > 15 || T <= 0) return -1;
+  VqArgs a{zE, cbn, cbn_sq, cb, weff, bias, residual, codes, T, C, cs, cd};
+  hipLaunchKernelGGL(vq_assign, dim3(T), dim3(256), 0, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -138,6 +138,79 @@ __global__ __launch_bounds__(256) void dec_reduce_ln(const float* __restrict__ p
 // With one wave per CU the weight stream is latency-bound (12 KB in flight per CU); NW = 4 quadruples the loads in flight.
 // (Cross-workgroup tickets were tried for fusing the split-K reduction + LayerNorm into this kernel: same-address device-scope atomics
 // from ~640 workgroups on 8 XCDs cost ~60 us per launch -- far more than the 5 us kernel boundary they would remove.)
+// fixed-order cross-wave sum of the NW waves' K-slices: waves 1.. park their fragments in LDS, wave 0 adds them in wave order and
+// is the only one to return true (it owns the epilogue)
+template <int NT, int NW>
+__device__ __forceinline__ bool skinny_wave_reduce(f32x4 (&acc)[NT][2], int wave, int lane) {
+  if (NW == 1) return true;
+  __shared__ f32x4 red[(NW > 1 ? NW - 1 : 1) * NT * 2 * 64];
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) red[(((wave - 1) * NT + t) * 2 + mt) * 64 + lane] = acc[t][mt];
+  }
+  __syncthreads();
+  if (wave > 0) return false;
+#pragma unroll
+  for (int w2 = 1; w2 < NW; ++w2)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const f32x4 o = red[(((w2 - 1) * NT + t) * 2 + mt) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][mt][j] += o[j];
+      }
+  return true;
+}
+
+// lane holds C[m = m0 + mt*16 + r][n = n0 + 16t + 4c + j]
+template <typename T, int MODE, int NT>
+__device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane) {
+  const int r = lane & 15, c = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + 4 * c;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = m0 + mt * 16 + r;
+      if (m >= a.M) continue;
+      const f32x4 av = acc[t][mt];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (n + j >= a.N) continue;
+        float v = av[j];
+        if (MODE == SK_PARTIAL) {
+          reinterpret_cast<float*>(a.out)[((int64_t)split * a.M + m) * a.N + n + j] = v;
+          continue;
+        }
+        if (a.bias) v += a.bias[n + j];
+        if (MODE == SK_SWIGLU) {   // interleaved rows: even column = gate, odd column = up
+          if (j & 1) continue;
+          float u = av[j + 1];
+          if (a.bias) u += a.bias[n + j + 1];
+          const float sg = v / (1.0f + __expf(-v));
+          reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + ((n + j) >> 1)] = T::from_f32(sg * u);
+          continue;
+        }
+        if (a.act == MIA_ACT_GELU) v = gelu_erf(v);
+        if (MODE == SK_OUTF32) reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n + j] = v;
+        else if (MODE == SK_OUT16) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + n + j] = T::from_f32(v);
+        else {  // SK_QKV: [0,D) -> q, [D,2D) -> self K cache, [2D,3D) -> self V cache at position pos
+          const int nn = n + j;
+          if (nn < a.D) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + nn] = T::from_f32(v);
+          else {
+            const int hd = (nn - a.D) % a.D, h = hd >> 6, d = hd & 63;
+            uint16_t* cache = nn < 2 * a.D ? a.cache_k : a.cache_v;
+            cache[(((int64_t)m * a.H + h) * a.n_ctx + a.pos[m]) * 64 + d] = T::from_f32(v);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int MODE, int NT, int KB, int NW>
 __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -216,68 +289,102 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
       acc[n][1] = T::mfma16(fw, fa1, acc[n][1]);
     }
   }
-  if (NW > 1) {   // fixed-order cross-wave sum: waves 1.. park their fragments in LDS, wave 0 adds them in wave order
-    __shared__ f32x4 red[(NW > 1 ? NW - 1 : 1) * NT * 2 * 64];
-    if (wave > 0) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) red[(((wave - 1) * NT + t) * 2 + mt) * 64 + lane] = acc[t][mt];
-    }
-    __syncthreads();
-    if (wave > 0) return;
-#pragma unroll
-    for (int w2 = 1; w2 < NW; ++w2)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const f32x4 o = red[(((w2 - 1) * NT + t) * 2 + mt) * 64 + lane];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[t][mt][j] += o[j];
-        }
-  }
-  // lane holds C[m = m0 + mt*16 + r][n = n0 + 16t + 4c + j]
+  if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
+  skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same skinny GEMM on MLX-affine 4-bit weights (group 64: w = scale * code + bias), de-quantised IN REGISTERS: the step streams
+// 4.5 bits per weight from HBM instead of 16 (Orpheus-3B: 1.9 GB instead of 6.6 GB per token).  Replaces MLX's quantizedMatmul on the
+// reference's default checkpoints (TTS/Orpheus/TTSEngine/OrpheusWeightLoader.swift:28-60, STT/Whisper/WhisperModel.swift:189-200).
+//
+// HBM layout (built once at load, lm.hip): the packed words are stored in MFMA FRAGMENT order --
+//   wfrag [tile = n/16][blk = k/128][lane = 16 c + r][4 words]: word s of lane (r, c) = codes of W[16 tile + r][128 blk + 32 s + 8 c .. +7]
+//   (K-step s of the block, exactly the 8 inputs the lane feeds to v_mfma_f32_16x16x32), so a wave reads one coalesced 1 KB line per
+//   16 rows x 128 inputs and the K order of every accumulation is the dense kernel's;
+//   sbfrag [tile][blk][r][4] 16-bit: (scale, bias) of the block's two 64-input groups for row 16 tile + r (steps 0,1 / 2,3).
+// Each value is expanded as RNE_16bit(fmaf(scale, code, bias)) -- bit for bit the tensor mia_dequant_affine + the dense loader produce --
+// so logits are IDENTICAL to the expanded-checkpoint path (asserted in tests/test_lm_gpu.py), whatever the split.
+// ------------------------------------------------------------------------------------------------
+struct Q4Frag { const uint32_t* wfrag; const uint16_t* sbfrag; int sdt; };
+
+template <typename T, int MODE, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_q4(SkinnyArgs a, Q4Frag q) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile0 = blockIdx.x * NT;
+  const int n0 = tile0 * 16;
+  const int split = blockIdx.y;
+  const int m0 = blockIdx.z * 32;
+  const int nblk = a.K >> 7;                      // 128-input blocks per row
+  const int bc = nblk / (a.S * NW);               // blocks per wave
+  const int b0 = (split * NW + wave) * bc;
+  const int n_tiles = (a.N + 15) >> 4;
+  const int r = lane & 15, c = lane >> 4;
+  int am0 = m0 + r; am0 = am0 < a.M ? am0 : a.M - 1;
+  int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
+  const uint16_t* ap0 = a.A + (int64_t)am0 * a.lda + 8 * c;
+  const uint16_t* ap1 = a.A + (int64_t)am1 * a.lda + 8 * c;
+  const u32x4* wp[NT];
+  const u32x2* sp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int n = n0 + 16 * t + 4 * c;
+    const int tl = tile0 + t < n_tiles ? tile0 + t : n_tiles - 1;      // tiles past the end re-read the last one and are never stored
+    wp[t] = reinterpret_cast<const u32x4*>(q.wfrag) + ((int64_t)tl * nblk) * 64 + lane;
+    sp[t] = reinterpret_cast<const u32x2*>(q.sbfrag) + ((int64_t)tl * nblk) * 16 + r;
+  }
+  f32x4 acc[NT][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int m = m0 + mt * 16 + r;
-      if (m >= a.M) continue;
-      const f32x4 av = acc[t][mt];
+  for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  struct Blk { u32x4 w[NT]; u32x2 sb[NT]; s16x8 a0[4], a1[4]; };
+  auto load_blk = [&](Blk& b, int blk) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (n + j >= a.N) continue;
-        float v = av[j];
-        if (MODE == SK_PARTIAL) {
-          reinterpret_cast<float*>(a.out)[((int64_t)split * a.M + m) * a.N + n + j] = v;
-          continue;
+    for (int t = 0; t < NT; ++t) { b.w[t] = wp[t][(int64_t)blk * 64]; b.sb[t] = sp[t][(int64_t)blk * 16]; }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      b.a0[st] = *reinterpret_cast<const s16x8*>(ap0 + (int64_t)blk * 128 + 32 * st);
+      b.a1[st] = *reinterpret_cast<const s16x8*>(ap1 + (int64_t)blk * 128 + 32 * st);
+    }
+  };
+  auto cvt = [&](uint32_t h16) -> float { return q.sdt == MIA_F16 ? F16::to_f32((uint16_t)h16) : BF16::to_f32((uint16_t)h16); };
+  auto mma_blk = [&](const Blk& b) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float sc[2] = {cvt(b.sb[t][0] & 0xffffu), cvt(b.sb[t][1] & 0xffffu)};
+      const float bs[2] = {cvt(b.sb[t][0] >> 16), cvt(b.sb[t][1] >> 16)};
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const uint32_t word = b.w[t][st];
+        const float s1 = sc[st >> 1], b1 = bs[st >> 1];
+        uint32_t pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = __builtin_fmaf(s1, (float)((word >> (8 * j)) & 15u), b1);
+          const float hi = __builtin_fmaf(s1, (float)((word >> (8 * j + 4)) & 15u), b1);
+          pk[j] = pack2<T>(lo, hi);
         }
-        if (a.bias) v += a.bias[n + j];
-        if (MODE == SK_SWIGLU) {   // interleaved rows: even column = gate, odd column = up
-          if (j & 1) continue;
-          float u = av[j + 1];
-          if (a.bias) u += a.bias[n + j + 1];
-          const float sg = v / (1.0f + __expf(-v));
-          reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + ((n + j) >> 1)] = T::from_f32(sg * u);
-          continue;
-        }
-        if (a.act == MIA_ACT_GELU) v = gelu_erf(v);
-        if (MODE == SK_OUTF32) reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n + j] = v;
-        else if (MODE == SK_OUT16) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + n + j] = T::from_f32(v);
-        else {  // SK_QKV: [0,D) -> q, [D,2D) -> self K cache, [2D,3D) -> self V cache at position pos
-          const int nn = n + j;
-          if (nn < a.D) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + nn] = T::from_f32(v);
-          else {
-            const int hd = (nn - a.D) % a.D, h = hd >> 6, d = hd & 63;
-            uint16_t* cache = nn < 2 * a.D ? a.cache_k : a.cache_v;
-            cache[(((int64_t)m * a.H + h) * a.n_ctx + a.pos[m]) * 64 + d] = T::from_f32(v);
-          }
-        }
+        const s16x8 fw = __builtin_bit_cast(s16x8, (u32x4){pk[0], pk[1], pk[2], pk[3]});
+        acc[t][0] = T::mfma16(fw, b.a0[st], acc[t][0]);
+        acc[t][1] = T::mfma16(fw, b.a1[st], acc[t][1]);
       }
     }
+  };
+  // ring of three register blocks (each 4 K-steps deep): two blocks of loads stay in flight behind the one being expanded
+  Blk k0, k1, k2;
+  if (bc > 0) load_blk(k0, b0);
+  if (bc > 1) load_blk(k1, b0 + 1);
+  for (int i = 0; i < bc; i += 3) {
+    if (i + 2 < bc) load_blk(k2, b0 + i + 2);
+    mma_blk(k0);
+    if (i + 1 >= bc) break;
+    if (i + 3 < bc) load_blk(k0, b0 + i + 3);
+    mma_blk(k1);
+    if (i + 2 >= bc) break;
+    if (i + 4 < bc) load_blk(k1, b0 + i + 4);
+    mma_blk(k2);
   }
+  if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
+  skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,6 +989,41 @@ int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) 
   if (mode == SK_SWIGLU && (a.N & 3)) return -1;
   if (dtype == MIA_F16) skinny_launch_t<F16>(a, mode, s); else skinny_launch_t<BF16>(a, mode, s);
   return 0;
+}
+
+
+template <typename T>
+static void skinny_q4_launch_t(const SkinnyArgs& a, const Q4Frag& q, int mode, hipStream_t s) {
+  const int tiles = (a.N + 15) / 16, nblk = a.K / 128;
+  const bool nw4 = nblk % (4 * a.S) == 0;
+  if (mode == SK_OUTF32) {   // vocabulary-wide head: 4 tiles per wave (activation fragments are reused 4 times)
+    dim3 grid((tiles + 3) / 4, a.S, (a.M + 31) / 32);
+    hipLaunchKernelGGL((skinny_gemm_q4<T, SK_OUTF32, 4, 1>), grid, dim3(64), 0, s, a, q);
+    return;
+  }
+  dim3 grid(tiles, a.S, (a.M + 31) / 32);
+#define Q4_LAUNCH(MODE_)                                                                                   \
+  do {                                                                                                     \
+    if (nw4) hipLaunchKernelGGL((skinny_gemm_q4<T, MODE_, 1, 4>), grid, dim3(256), 0, s, a, q);             \
+    else hipLaunchKernelGGL((skinny_gemm_q4<T, MODE_, 1, 1>), grid, dim3(64), 0, s, a, q);                  \
+  } while (0)
+  switch (mode) {
+    case SK_OUT16: Q4_LAUNCH(SK_OUT16); break;
+    case SK_SWIGLU: Q4_LAUNCH(SK_SWIGLU); break;
+    default: Q4_LAUNCH(SK_PARTIAL); break;
+  }
+#undef Q4_LAUNCH
+}
+
+// 4-bit form of skinny_gemm_launch: a.W is ignored, the weights come from the fragment-ordered arrays (see skinny_gemm_q4)
+int skinny_gemm_q4_launch(const SkinnyArgs& a, const uint32_t* wfrag, const uint16_t* sbfrag, int scale_dtype, int mode, int dtype, hipStream_t s) {
+  if (a.K % (128 * a.S) != 0 || a.lda % 8 != 0 || !wfrag || !sbfrag) return -1;
+  if (scale_dtype != MIA_F16 && scale_dtype != MIA_BF16) return -1;
+  if (mode != SK_OUT16 && mode != SK_OUTF32 && mode != SK_PARTIAL && mode != SK_SWIGLU) return -1;
+  if (mode == SK_SWIGLU && (a.N & 3)) return -1;
+  const Q4Frag q{wfrag, sbfrag, scale_dtype};
+  if (dtype == MIA_F16) skinny_q4_launch_t<F16>(a, q, mode, s); else skinny_q4_launch_t<BF16>(a, q, mode, s);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s) { return skinny_gemm_launch(a, mode, w->dtype, s); }

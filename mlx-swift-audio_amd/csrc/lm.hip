@@ -24,7 +24,11 @@ struct LmState { int pos; int n_hist; int finished; int n_gen; int n_embeds; int
 
 struct RasParams { float top_p; int top_k; int win; float tau; int eos; int min_len; int max_len; int n_uniforms; };
 
+// MLX-affine 4-bit copy of one fused matrix in MFMA fragment order (decode_kernels.hip: skinny_gemm_q4); null = use the 16-bit weights
+struct Q4W { uint32_t* wfrag = nullptr; uint16_t* sbfrag = nullptr; };
+
 struct LmLayer {
+  Q4W q_qkv, q_o, q_gu, q_down;
   float* in_norm = nullptr; float* post_norm = nullptr;
   void* wqkv = nullptr; float* bqkv = nullptr;   // [(Hq+2Hkv)*dh][hidden]
   void* wo = nullptr;                            // [hidden][Hq*dh]
@@ -39,6 +43,9 @@ struct mia_lm {
   std::vector<void*> allocs;
   void* embed = nullptr;        // 16-bit [V][hidden]
   void* lm_head = nullptr;      // 16-bit [V][hidden] (== embed when tied)
+  Q4W q_head;                   // 4-bit copy of lm_head (mia_lm_attach_q4)
+  int q4_scale_dtype = 0;       // MIA_F16 | MIA_BF16: storage type of the checkpoint's scales / biases
+  bool q4 = false;              // the step GEMVs stream the packed weights
   float* head_bias = nullptr;   // optional (CosyVoice2 llm_decoder)
   int head_vocab = 0;           // rows of lm_head (CosyVoice2: speech vocabulary + 3)
   void* gen_embed = nullptr;    // 16-bit [rows][hidden]: embedding of GENERATED ids when it differs from embed (speech_embedding)
@@ -957,8 +964,9 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
   const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh, Nqkv = Nq + 2 * Nk;
   const bool f16 = m->dtype == MIA_F16;
   // nb sequences = nb rows of every skinny GEMM: the weights are still read once per step
-  auto skinny = [&](const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int N, int K, int S, int mode) {
+  auto skinny = [&](const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int N, int K, int S, int mode, const Q4W* qw = nullptr) {
     SkinnyArgs a{(const uint16_t*)A, lda, (const uint16_t*)W, bias, out, ldo, nullptr, nullptr, nullptr, nb, N, K, S, MIA_ACT_NONE, 0, 0, 0};
+    if (m->q4 && qw && qw->wfrag) return skinny_gemm_q4_launch(a, qw->wfrag, qw->sbfrag, m->q4_scale_dtype, mode, m->dtype, s);
     return skinny_gemm_launch(a, mode, m->dtype, s);
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
@@ -968,17 +976,17 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
     const LmLayer& L = m->layers[l];
     uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * layer_stride;
     uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * layer_stride;
-    if (skinny(m->h, D, L.wqkv, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL)) return -1;
+    if (skinny(m->h, D, L.wqkv, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL, &L.q_qkv)) return -1;
     lm_launch_attention(m, true, nb, nullptr, kc, vc, m->att, nullptr, m->qkv_part, m->S_qkv, L.bqkv);      // RoPE + cache row + attention
-    if (skinny(m->att, Nq, L.wo, nullptr, m->partial, 0, D, Nq, m->S_o, SK_PARTIAL)) return -1;
+    if (skinny(m->att, Nq, L.wo, nullptr, m->partial, 0, D, Nq, m->S_o, SK_PARTIAL, &L.q_o)) return -1;
     LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_o, L.post_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
-    if (skinny(m->h, D, L.wgu, nullptr, m->act, c.inter, 2 * c.inter, D, 1, SK_SWIGLU)) return -1;
-    if (skinny(m->act, c.inter, L.wdown, nullptr, m->partial, 0, D, c.inter, m->S_down, SK_PARTIAL)) return -1;
+    if (skinny(m->h, D, L.wgu, nullptr, m->act, c.inter, 2 * c.inter, D, 1, SK_SWIGLU, &L.q_gu)) return -1;
+    if (skinny(m->act, c.inter, L.wdown, nullptr, m->partial, 0, D, c.inter, m->S_down, SK_PARTIAL, &L.q_down)) return -1;
     LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_down, l + 1 < c.n_layers ? m->layers[l + 1].in_norm : m->final_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
   }
 #undef LAUNCH_T
   const int HV = m->head_vocab > 0 ? m->head_vocab : c.vocab;
-  if (skinny(m->h, D, m->lm_head, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32)) return -1;
+  if (skinny(m->h, D, m->lm_head, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32, &m->q_head)) return -1;
   if (ras) hipLaunchKernelGGL(lm_sample_ras, dim3(nb), dim3(1024), 0, s, m->logits, HV, m->tokens, m->out_tokens, m->uniforms, m->state, *ras, c.max_ctx);
   else if (sampling) { if (lm_sample_launch(s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx, nb)) return -1; }
   else hipLaunchKernelGGL(lm_advance, dim3(nb), dim3(1), 0, s, m->state);
@@ -1221,6 +1229,109 @@ extern "C" mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia
   if (lm_alloc_state(m, 1)) return fail(m, "hipMalloc failed (state buffers)");
   if (hipDeviceSynchronize() != hipSuccess) return fail(m, "device error during upload");
   return m;
+}
+
+// ---- MLX-affine 4-bit weights for the decode step (OrpheusWeightLoader.swift:28-60: the reference's default checkpoints are q4, group 64) ----
+namespace {
+
+struct Q4Src { const uint32_t* w; const uint16_t* s; const uint16_t* b; };   // one Linear as stored: packed [N][K/8], scales / biases [N][K/64]
+
+// rows[i] = (tensor index, row): the fused matrix's row i.  Builds the fragment-ordered arrays (layout: skinny_gemm_q4) and uploads them.
+bool q4_repack(LmLoader& L, const std::vector<Q4Src>& src, const std::vector<std::pair<int, int>>& rows, int K, Q4W& out) {
+  const int N = (int)rows.size(), tiles = (N + 15) / 16, nblk = K / 128, wpr = K / 8, gpr = K / 64;
+  std::vector<uint32_t> wf((size_t)tiles * nblk * 64 * 4);
+  std::vector<uint16_t> sb((size_t)tiles * nblk * 16 * 4);
+  for (int t = 0; t < tiles; ++t)
+    for (int r = 0; r < 16; ++r) {
+      const int n = std::min(t * 16 + r, N - 1);                      // the last tile repeats its final row (never stored)
+      const Q4Src& q = src[rows[n].first];
+      const uint32_t* wrow = q.w + (size_t)rows[n].second * wpr;
+      const uint16_t* srow = q.s + (size_t)rows[n].second * gpr;
+      const uint16_t* brow = q.b + (size_t)rows[n].second * gpr;
+      for (int b = 0; b < nblk; ++b) {
+        for (int c = 0; c < 4; ++c)
+          for (int st = 0; st < 4; ++st) wf[(((size_t)t * nblk + b) * 64 + 16 * c + r) * 4 + st] = wrow[b * 16 + 4 * st + c];
+        uint16_t* d = &sb[(((size_t)t * nblk + b) * 16 + r) * 4];
+        d[0] = srow[2 * b]; d[1] = brow[2 * b]; d[2] = srow[2 * b + 1]; d[3] = brow[2 * b + 1];
+      }
+    }
+  out.wfrag = (uint32_t*)L.dev(wf.size() * 4);
+  out.sbfrag = (uint16_t*)L.dev(sb.size() * 2);
+  if (!out.wfrag || !out.sbfrag) return false;
+  (void)hipMemcpy(out.wfrag, wf.data(), wf.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(out.sbfrag, sb.data(), sb.size() * 2, hipMemcpyHostToDevice);
+  return true;
+}
+
+}  // namespace
+
+// tensors: for every Linear of the step, `<name>.weight` (MIA_U32 packed codes [N][K/8]), `<name>.scales`, `<name>.biases` ([N][K/64],
+// both MIA_F16 or both MIA_BF16), names as in the checkpoint (model.layers.L.self_attn.{q,k,v,o}_proj, mlp.{gate,up,down}_proj,
+// model.embed_tokens / lm_head).  The handle must already hold the de-quantised 16-bit weights (mia_lm_load on the expanded
+// checkpoint): the batched prompt pass keeps using them, the per-token step switches to the packed form.
+extern "C" int mia_lm_attach_q4(mia_lm* m, const mia_tensor_view* tensors, int n_tensors, int group_size) {
+  if (!m) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = m->ctx;
+  MIA_CHECK_ARG(ctx, tensors && n_tensors > 0 && group_size == 64, "lm_attach_q4: tensors required, group size must be 64");
+  const mia_lm_config& c = m->cfg;
+  const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh;
+  MIA_CHECK_ARG(ctx, D % 128 == 0 && Nq % 128 == 0 && c.inter % 128 == 0, "lm_attach_q4: hidden, n_heads*head_dim and inter must be multiples of 128");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  LmLoader L; L.m = m;
+  for (int i = 0; i < n_tensors; ++i) if (tensors[i].name && tensors[i].data) L.by_name[tensors[i].name] = &tensors[i];
+  int sdt = 0;
+  auto get = [&](const std::string& p, int N, int K, Q4Src& q) -> bool {
+    const mia_tensor_view* w = L.find(p + ".weight"); const mia_tensor_view* s = L.find(p + ".scales"); const mia_tensor_view* b = L.find(p + ".biases");
+    if (!w || !s || !b) return false;
+    const bool ok = w->dtype == MIA_U32 && w->ndim == 2 && w->shape[0] == N && w->shape[1] == K / 8 && s->ndim == 2 && s->shape[0] == N && s->shape[1] == K / 64 &&
+                    b->ndim == 2 && b->shape[0] == N && b->shape[1] == K / 64 && s->dtype == b->dtype && (s->dtype == MIA_F16 || s->dtype == MIA_BF16);
+    if (!ok) { if (L.err.empty()) L.err = "'" + p + "' is not a 4-bit group-64 Linear of the expected shape (scales / biases must be f16 or bf16)"; return false; }
+    if (sdt == 0) sdt = s->dtype;
+    if (sdt != s->dtype) { if (L.err.empty()) L.err = "mixed scale dtypes"; return false; }
+    q = Q4Src{(const uint32_t*)w->data, (const uint16_t*)s->data, (const uint16_t*)b->data};
+    return true;
+  };
+  auto seq = [](int tensor, int n, std::vector<std::pair<int, int>>& rows) { for (int i = 0; i < n; ++i) rows.push_back({tensor, i}); };
+  for (int l = 0; l < c.n_layers && L.err.empty(); ++l) {
+    const std::string p = "model.layers." + std::to_string(l);
+    LmLayer& ly = m->layers[l];
+    std::vector<Q4Src> src(3);
+    std::vector<std::pair<int, int>> rows;
+    if (get(p + ".self_attn.q_proj", Nq, D, src[0]) && get(p + ".self_attn.k_proj", Nk, D, src[1]) && get(p + ".self_attn.v_proj", Nk, D, src[2])) {
+      seq(0, Nq, rows); seq(1, Nk, rows); seq(2, Nk, rows);
+      if (!q4_repack(L, src, rows, D, ly.q_qkv)) break;
+    }
+    src.assign(1, Q4Src{}); rows.clear();
+    if (get(p + ".self_attn.o_proj", D, Nq, src[0])) { seq(0, D, rows); if (!q4_repack(L, src, rows, Nq, ly.q_o)) break; }
+    src.assign(2, Q4Src{}); rows.clear();
+    if (get(p + ".mlp.gate_proj", c.inter, D, src[0]) && get(p + ".mlp.up_proj", c.inter, D, src[1])) {
+      for (int i = 0; i < c.inter; ++i) { rows.push_back({0, i}); rows.push_back({1, i}); }      // gate / up rows interleaved like wgu
+      if (!q4_repack(L, src, rows, D, ly.q_gu)) break;
+    }
+    src.assign(1, Q4Src{}); rows.clear();
+    if (get(p + ".mlp.down_proj", D, c.inter, src[0])) { seq(0, D, rows); if (!q4_repack(L, src, rows, c.inter, ly.q_down)) break; }
+  }
+  if (L.err.empty() && m->head_vocab == 0) {     // the tied / plain LM head (the CosyVoice2 speech head stays 16-bit: it is not quantised there)
+    std::vector<Q4Src> src(1);
+    std::vector<std::pair<int, int>> rows;
+    const std::string hp = c.tie_embeddings ? "model.embed_tokens" : "lm_head";
+    if (L.find(hp + ".scales", false)) { if (get(hp, c.vocab, D, src[0])) { seq(0, c.vocab, rows); q4_repack(L, src, rows, D, m->q_head); } }
+  }
+  if (!L.err.empty()) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "lm_attach_q4: %s", L.err.c_str());
+  MIA_HIP(ctx, hipDeviceSynchronize());
+  m->q4_scale_dtype = sdt;
+  m->q4 = true;
+  m->graph_mode = -1;          // the captured step holds the 16-bit launches: re-capture
+  return MIA_OK;
+}
+
+// switch the step between the packed (1) and the 16-bit (0) weights of a handle that has both (A/B timing, parity tests)
+extern "C" int mia_lm_use_q4(mia_lm* m, int on) {
+  if (!m) return MIA_ERR_MODEL_NOT_LOADED;
+  MIA_CHECK_ARG(m->ctx, !on || m->q4_scale_dtype != 0, "lm_use_q4: no packed weights attached");
+  m->q4 = on != 0;
+  m->graph_mode = -1;
+  return MIA_OK;
 }
 
 extern "C" int mia_lm_reset(mia_lm* m) {

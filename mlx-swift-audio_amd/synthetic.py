@@ -166,10 +166,12 @@ class DACConfig:
     n_codebooks: int = 2
     codebook_size: int = 1024
     codebook_dim: int = 8
+    encoder_dim: int = 64                      # DACEncoder(dModel:) ; latent = encoder_dim * 2^len(encoder_rates)
+    encoder_rates: tuple = (2, 4, 5, 8)        # hop length 320 (DACModel.swift:192-202)
 
 
 SNAC_CONFIGS = {"snac_24khz": SNACConfig(), "snac_micro": SNACConfig(64, 128, (4, 2), (2, 1), 64, 8), "snac_micro_cn": SNACConfig(64, 128, (4, 2), (2, 1), 64, 8, noise_channels=-1)}
-DAC_CONFIGS = {"dac_speech": DACConfig(), "dac_micro": DACConfig(64, 128, (4, 5), 2, 64, 8)}
+DAC_CONFIGS = {"dac_speech": DACConfig(), "dac_micro": DACConfig(64, 128, (4, 5), 2, 64, 8, 32, (4,))}
 
 
 def _wn_pair(rng, shape, norm_axes, g_shape):
@@ -267,6 +269,27 @@ def dac_weights(cfg: DACConfig, seed: int = 0) -> dict[str, np.ndarray]:
     n = len(cfg.decoder_rates)
     alpha(f"{P}{1 + n}.alpha", cin)
     conv(f"{P}{2 + n}", 1, 7, cin)
+    # ---- encoder (DACModel.swift:13-86) + the quantizers' in_proj (DACQuantize.swift:37-41); drawn AFTER the decoder tensors so that
+    # the decoder-side values of a given seed are the ones earlier fixtures were made with
+    E = "encoder.block.layers."
+    conv(E + "0", cfg.encoder_dim, 7, 1)
+    c = cfg.encoder_dim
+    for i, st in enumerate(cfg.encoder_rates):
+        b = f"{E}{1 + i}.block.layers."
+        for r in range(3):
+            u = f"{b}{r}.block.layers."
+            alpha(u + "0.alpha", c)
+            conv(u[:-1] + ".1", c, 7, c)
+            alpha(u + "2.alpha", c)
+            conv(u[:-1] + ".3", c, 1, c)
+        alpha(b + "3.alpha", c)
+        conv(b + "4", 2 * c, 2 * st, c)
+        c *= 2
+    ne = len(cfg.encoder_rates)
+    alpha(f"{E}{1 + ne}.alpha", c)
+    conv(f"{E}{2 + ne}", cfg.latent_dim, 3, c)
+    for i in range(cfg.n_codebooks):
+        conv(f"quantizer.quantizers.{i}.in_proj", cfg.codebook_dim, 1, cfg.latent_dim)
     return w
 
 

@@ -135,11 +135,63 @@ class DACOracle:
         self.cfg = cfg
         self.w = {k: _t(v) for k, v in weights.items()}
 
-    def _wnconv(self, p, x, padding=0, dilation=1):
+    def _wnconv(self, p, x, padding=0, dilation=1, stride=1):
         W = self.w
         v, g = W[p + ".weight_v"], W[p + ".weight_g"]
         weight = g * v / (_norm_except(v, 0) + 1e-12)                      # DACLayers.swift:106-107
-        return _conv1d_cf(x, weight, W[p + ".bias"], padding=padding, dilation=dilation)
+        return _conv1d_cf(x, weight, W[p + ".bias"], stride=stride, padding=padding, dilation=dilation)
+
+    def _res_unit(self, u, y, d):
+        """DACResidualUnit (DACLayers.swift:198-235): snake -> conv7 dilated -> snake -> conv1 -> + x."""
+        W = self.w
+        t = _snake(y, W[u + "0.alpha"].reshape(1, -1, 1))
+        t = self._wnconv(u[:-1] + ".1", t, padding=3 * d, dilation=d)
+        t = _snake(t, W[u + "2.alpha"].reshape(1, -1, 1))
+        return y + self._wnconv(u[:-1] + ".3", t)
+
+    def encode(self, audio: np.ndarray, n_quantizers: int | None = None):
+        """DACCodec.encode (DACModel.swift:284-296) for one mono sequence: preprocess (right-pad to the hop length, :308-317) ->
+        DACEncoder (:43-86, blocks :15-38) -> residual vector quantisation (DACQuantize.swift:147-190, nearest entry on L2-normalised
+        vectors :87-115).  Returns (codes int32 [n_q, T'], gaps float32 [n_q, T'] = second-best minus best distance of every
+        choice: oracle-only diagnostic, a 16-byte-different matmul may pick the runner-up only where the gap is ~0)."""
+        cfg, W = self.cfg, self.w
+        hop = int(np.prod(cfg.encoder_rates))
+        x = np.asarray(audio, np.float32).reshape(-1)
+        pad = -(-x.shape[0] // hop) * hop - x.shape[0]
+        y = _t(np.pad(x, (0, pad)))[None, None, :]
+        E = "encoder.block.layers."
+        y = self._wnconv(E + "0", y, padding=3)
+        for i, st in enumerate(cfg.encoder_rates):
+            b = f"{E}{1 + i}.block.layers."
+            for r, d in enumerate((1, 3, 9)):
+                y = self._res_unit(f"{b}{r}.block.layers.", y, d)
+            y = _snake(y, W[b + "3.alpha"].reshape(1, -1, 1))
+            y = self._wnconv(b + "4", y, padding=int(np.ceil(st / 2.0)), stride=st)
+        ne = len(cfg.encoder_rates)
+        y = _snake(y, W[f"{E}{1 + ne}.alpha"].reshape(1, -1, 1))
+        z = self._wnconv(f"{E}{2 + ne}", y, padding=1)                     # [1, latent, T']
+
+        def l2n(a):                                                        # l2Normalize (DACQuantize.swift:14-20), dim 1
+            n = torch.pow(torch.sum(torch.pow(torch.abs(a), 2), dim=1, keepdim=True), 0.5)
+            return a / torch.maximum(n, torch.tensor(1e-12))
+
+        nq = cfg.n_codebooks if n_quantizers is None else min(n_quantizers, cfg.n_codebooks)
+        residual, codes, gaps = z, [], []
+        for i in range(nq):
+            q = f"quantizer.quantizers.{i}"
+            zE = self._wnconv(q + ".in_proj", residual)                   # [1, cb_dim, T']
+            enc = zE[0].t()
+            cb = W[q + ".codebook.weight"]
+            en, cn = l2n(enc), l2n(cb)
+            dist = torch.sum(en ** 2, dim=1, keepdim=True) - 2 * en @ cn.t() + torch.sum(cn ** 2, dim=1, keepdim=True).t()
+            idx = torch.argmax(-dist, dim=1)
+            two = torch.topk(-dist, 2, dim=1).values
+            gaps.append((two[:, 0] - two[:, 1]).numpy())
+            zq_raw = cb[idx].t()[None]
+            zq = zE + (zq_raw - zE)                                        # straight-through form of the forward pass (:62)
+            residual = residual - self._wnconv(q + ".out_proj", zq)
+            codes.append(idx.numpy().astype(np.int32))
+        return np.stack(codes), np.stack(gaps).astype(np.float32)
 
     def decode_from_codes(self, codes: np.ndarray) -> np.ndarray:
         """DACCodec.decodeFromCodes: codes int [n_codebooks, T] (one sequence) -> float32 [samples]."""
@@ -159,12 +211,7 @@ class DACOracle:
             weight = g * v / (_norm_except(v, 2) + 1e-12)                    # DACLayers.swift:180-181
             y = _convt1d_cf(y, weight, W[b + "1.bias"], s, int(np.ceil(s / 2.0)))
             for r, d in enumerate((1, 3, 9)):
-                u = f"{b}{2 + r}.block.layers."
-                t = _snake(y, W[u + "0.alpha"].reshape(1, -1, 1))
-                t = self._wnconv(u[:-1] + ".1", t, padding=3 * d, dilation=d)
-                t = _snake(t, W[u + "2.alpha"].reshape(1, -1, 1))
-                t = self._wnconv(u[:-1] + ".3", t)
-                y = y + t
+                y = self._res_unit(f"{b}{2 + r}.block.layers.", y, d)
         n = len(cfg.decoder_rates)
         y = _snake(y, W[f"{P}{1 + n}.alpha"].reshape(1, -1, 1))
         y = self._wnconv(f"{P}{2 + n}", y, padding=3)
