@@ -101,6 +101,15 @@ int mia_mel_s3gen(mia_ctx* ctx, const float* pcm, int64_t n_samples, float* mel,
  * scale = to_rate / from_rate as float32; out holds mia_resample_linear_len(n_samples, scale) samples. */
 int64_t mia_resample_linear_len(int64_t n_samples, float scale);
 int mia_resample_linear(mia_ctx* ctx, const float* x, int64_t n_samples, float scale, float* out, int mem);
+/* Anti-aliased sample-rate conversion of input audio (e.g. 44.1 / 48 kHz files -> 16 kHz for Whisper, -> 24 kHz for the codecs).  The
+ * reference uses AVAudioConverter here (Audio/AudioResampler.swift:15-88), whose filter is not specified in its sources: this is a
+ * documented polyphase windowed-sinc interpolator (Kaiser beta 8.6, 16 zero crossings per side, roll-off 0.945, unit DC gain per
+ * phase; definition in csrc/resample.hip) -- a stated substitute, not a parity claim.  n_out = floor(n_samples * to / from)
+ * (mia_resample_sinc_len).  mia_resample_sinc_table returns the phase filters (float32 [L][taps], L = to / gcd) for inspection. */
+int64_t mia_resample_sinc_len(int64_t n_samples, int from_rate, int to_rate);
+int mia_resample_sinc_table(int from_rate, int to_rate, float* table, int capacity, int* L_out, int* taps_out);
+int mia_resample_sinc(mia_ctx* ctx, const float* x, int64_t n_samples, int from_rate, int to_rate, float* out, int64_t out_capacity,
+                      int64_t* n_out, int mem);
 
 /* ---- data-parallel exchange (SURVEY.md section 8b "multi-GPU", 8e) ------------------------------------------------- */
 /* Clips shard across the GPUs of one node (one process and one mia_ctx per GPU, full weight replica per rank); the path's only
@@ -450,6 +459,17 @@ int mia_flow_encode(mia_flow* f, const int32_t* token, int n_token, float* mu, i
  *   mel out float32 [80][T - prompt_feat_len] (channel-major, what CosyHiFTGenerator consumes).  Every buffer lives in `mem`. */
 int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
                        int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, float* mel, int mem);
+/* The same call with the two switches the modules carry for chunked synthesis:
+ *   finalize = 0 drops the encoder's last pre_lookahead_len * upsample_stride frames before the CFM (CosyVoice2Model.swift:504-510), so
+ *     T = upsample_stride (n_token + n_prompt) - that trim; z is [80][T] for THAT T and *mel_frames = T - prompt_feat_len;
+ *   enc_static_chunk / dec_static_chunk > 0 turn on the block-causal "streaming" attention masks (query i sees keys below
+ *     (i / chunk + 1) chunk: subsequentChunkMask, Codec/S3Gen/Transformer/UpsampleConformerEncoder.swift:124-195) of the conformer
+ *     encoder (chunk, and chunk * upsample_stride after the up-sampling, :424-460) and of the estimator's transformer blocks
+ *     (Codec/S3Gen/S3GenDecoder.swift:304-320); the checkpoint's values are encoder_static_chunk_size / decoder_static_chunk_size
+ *     (TTS/CosyVoice2/Config/CosyVoice2Config.swift:155,166).  0 / 0 with finalize = 1 is mia_flow_inference. */
+int mia_flow_inference_streaming(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
+                                 int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, int finalize, int enc_static_chunk,
+                                 int dec_static_chunk, float* mel, int* mel_frames, int mem);
 
 /* ---- CAM++ speaker encoder (CosyVoice2 prepareConditionals, once per speaker) ---------------------------------
  * Replaces CAMPlusSpeakerEncoder (TTS/CosyVoice2/SpeakerEncoder/CAMPlusSpeakerEncoder.swift:12-150, called at

@@ -19,7 +19,7 @@ ERR_OUT_OF_MEMORY = -4
 ERR_DEVICE = -5
 ERR_UNSUPPORTED = -6
 
-F32, F16, BF16 = 0, 1, 2
+F32, F16, BF16, U32 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 
 

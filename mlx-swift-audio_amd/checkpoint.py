@@ -119,3 +119,26 @@ def load_whisper_checkpoint(ctx: _lib.Context, model_dir: str):
     import os
     dims = load_model_dimensions(os.path.join(model_dir, "config.json"))
     return dims, expand_checkpoint(ctx, read_safetensors(os.path.join(model_dir, "model.safetensors")))
+
+
+def quantize_affine(w: np.ndarray, group_size: int = 64, bits: int = 4, scale_dtype=np.float16):
+    """MLX affine quantisation of one weight matrix, the direction the reference's loaders take for checkpoints that are not already
+    quantised (`quantize(model:) { (64, bits, .affine) }`, STT/Whisper/WhisperModel.swift:189-196): per group of `group_size`
+    consecutive inputs, scale = (max - min) / (2^bits - 1), bias = min, code = round((w - bias) / scale); codes packed little end
+    first into uint32 words.  Returns (codes uint32 [N, K*bits/32], scales, biases [N, K/group_size] in `scale_dtype`) -- the three
+    tensors a quantised checkpoint stores for the layer (feed them to CausalLM.attach_q4 / expand them with dequantize_affine)."""
+    w = np.asarray(w, np.float32)
+    n, k = w.shape
+    g = w.reshape(n, k // group_size, group_size)
+    lo, hi = g.min(-1), g.max(-1)
+    top = float((1 << bits) - 1)
+    scale = np.where(hi > lo, (hi - lo) / top, 1.0).astype(scale_dtype)
+    bias = lo.astype(scale_dtype)
+    s32 = scale.astype(np.float32)[..., None]
+    q = np.clip(np.rint((g - bias.astype(np.float32)[..., None]) / s32), 0, top).astype(np.uint32)
+    per = 32 // bits
+    q = q.reshape(n, k // per, per)
+    packed = np.zeros(q.shape[:2], np.uint32)
+    for j in range(per):
+        packed |= q[:, :, j] << np.uint32(j * bits)
+    return packed, scale, bias

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
   auto load_regs = [&](int key0) {
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
-      int key = key0 + 32 * s_tile + s_row + 4 * j; key = key < a.T ? key : a.T - 1;
+      int key = key0 + 32 * s_tile + s_row + 4 * j; key = key < a.T ? key : a.T - 1;      // (rows past the walk's end are clamped reads, masked later)
       rk[j] = *reinterpret_cast<const f32x4*>(K + (int64_t)key * a.ldk + s_c4);
       rv[j] = *reinterpret_cast<const f32x4*>(V + (int64_t)key * a.ldv + s_c4);
       if (POS) rp[j] = *reinterpret_cast<const f32x4*>(P + (int64_t)key * a.ldp + s_c4);
@@ -106,7 +106,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     for (int r = 0; r < 16; ++r) acc_o[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int npairs = (a.T + 32 * NKV - 1) / (32 * NKV);
+  // streaming mask: this lane's query sees keys below klim; the workgroup's key walk stops at its last query's limit
+  const int qmine = q0 + lq < a.T ? q0 + lq : a.T - 1;
+  const int klim = a.chunk > 0 ? min(a.T, (qmine / a.chunk + 1) * a.chunk) : a.T;
+  const int qlast = q0 + 31 < a.T ? q0 + 31 : a.T - 1;
+  const int Tk = a.chunk > 0 ? min(a.T, (qlast / a.chunk + 1) * a.chunk) : a.T;     // workgroup-uniform
+  const int npairs = (Tk + 32 * NKV - 1) / (32 * NKV);
   load_regs(0);
   for (int kp = 0; kp < npairs; ++kp) {
     const int key0 = kp * 32 * NKV + 32 * kvh;    // this wave's tile
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     write_lds();
     __syncthreads();
     if (kp + 1 < npairs) load_regs((kp + 1) * 32 * NKV);
-    if (key0 < a.T) {                             // (the odd tail tile may be absent: wave-uniform)
+    if (key0 < Tk) {                              // (the odd tail tile may be absent: wave-uniform)
 
     // ---- S^T = K Q^T
     f32x16 acc_s;
@@ -146,22 +151,24 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     // scalar array: writing elements back into the MFMA result vector made the compiler round-trip it through scratch memory.
     float pr[16];
     float mloc = -INFINITY;
-    const bool tail = key0 + 32 > a.T;
+    const bool tail = key0 + 32 > klim;           // per lane: keys at or beyond this query's limit are masked (klim == T without chunks)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float sv = acc_s[r];
-      if (tail && key0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.T) sv = -INFINITY;
+      if (tail && key0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= klim) sv = -INFINITY;
       pr[r] = sv;
       mloc = fmaxf(mloc, sv);
     }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    // a tile can be entirely beyond ONE lane's limit (chunk mask): keep that lane's state at "nothing seen" without producing NaNs
+    const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);
     m_run = m_new;
     float lsum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      pr[r] = __builtin_amdgcn_exp2f(pr[r] - m_new);
+      pr[r] = __builtin_amdgcn_exp2f(pr[r] - m_ref);
       lsum += pr[r];
     }
     l_run = l_run * alpha + lsum;
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
     float m = m_run;
 #pragma unroll
     for (int w2 = 0; w2 < NKV - 1; ++w2) m = fmaxf(m, lds[(w2 * 64 + lane) * 34]);
-    const float a0 = __builtin_amdgcn_exp2f(m_run - m);
+    const float a0 = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run - m);
     float den = l_run * a0;
 #pragma unroll
     for (int db = 0; db < 2; ++db)

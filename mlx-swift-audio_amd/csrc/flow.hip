@@ -330,13 +330,14 @@ size_t carve(mia_flow* f, int Tt, int T, int S, Bufs* b) {
 }
 
 // one ConformerEncoderLayer (ConformerEncoderLayer.swift:69-165): pre-norm rel-pos MHA + pre-norm SiLU FFN
-void conformer_layer(Run& r, const ConfLayer& l, Bufs& b, int T, int D, int H, int FF) {
+void conformer_layer(Run& r, const ConfLayer& l, Bufs& b, int T, int D, int H, int FF, int chunk = 0) {
   r.ln(l.n_mha, b.x, b.h, T, D, 1e-12f);
   r.gemm(l.qkv, b.h, D, T, b.qkv, 3 * D);
   r.gemm(l.pos, b.pe, D, T, b.pb, D);
   AttnF32Args a;
   a.q = b.qkv; a.ldq = 3 * D; a.k = b.qkv + D; a.ldk = 3 * D; a.v = b.qkv + 2 * D; a.ldv = 3 * D; a.p = b.pb; a.ldp = D;
   a.bias_u = l.u; a.bias_v = l.v; a.out = b.att; a.ldo = D; a.B = 1; a.T = T; a.H = H; a.scale = 1.0f / sqrtf((float)(D / H));
+  a.chunk = chunk;
   r.attn(a);
   r.gemm(l.out, b.att, D, T, b.x, D, 0, b.x);
   r.ln(l.n_ff, b.x, b.h, T, D, 1e-12f);
@@ -345,7 +346,7 @@ void conformer_layer(Run& r, const ConfLayer& l, Bufs& b, int T, int D, int H, i
 }
 
 // tokens (device) -> mu [T][80]
-int run_encoder(mia_flow* f, Bufs& b, const int32_t* d_ids, int Tt) {
+int run_encoder(mia_flow* f, Bufs& b, const int32_t* d_ids, int Tt, int chunk = 0) {
   const mia_flow_config& c = f->cfg;
   const int D = c.input_size, H = c.enc_heads, FF = c.enc_linear_units, st = c.upsample_stride, T = Tt * st;
   Run r{f, f->ctx->stream};
@@ -358,13 +359,13 @@ int run_encoder(mia_flow* f, Bufs& b, const int32_t* d_ids, int Tt) {
   // PreLookaheadLayer: conv1 over x[t .. t+L] (zero beyond the end) -> leaky-ReLU -> causal conv2 (k 3) -> + x
   r.gemm(f->pl1, b.x0, D, Tt, b.h, D, 5, nullptr, 0);
   r.gemm(f->pl2, b.h, D, Tt, b.x, D, 0, b.x0, 2);
-  for (const ConfLayer& l : f->enc) conformer_layer(r, l, b, Tt, D, H, FF);
+  for (const ConfLayer& l : f->enc) conformer_layer(r, l, b, Tt, D, H, FF, chunk);
   // Upsample1D: nearest repeat x stride, left pad 2 stride, conv k = 2 stride + 1
   hipLaunchKernelGGL(flow_repeat_rows, dim3((unsigned)(((int64_t)T * (D / 4) + 255) / 256)), dim3(256), 0, s, b.x, b.att, T, D, st);
   r.gemm(f->up_conv, b.att, D, T, b.h, D, 0, nullptr, 2 * st);
   r.gemm(f->up_embed, b.h, D, T, b.x0, D);
   r.ln(f->up_embed_n, b.x0, b.x, T, D, 1e-5f);
-  for (const ConfLayer& l : f->up_enc) conformer_layer(r, l, b, T, D, H, FF);
+  for (const ConfLayer& l : f->up_enc) conformer_layer(r, l, b, T, D, H, FF, chunk * st);      // effectiveUpChunkSize (:452)
   r.ln(f->after_n, b.x, b.h, T, D, 1e-5f);
   r.gemm(f->enc_proj, b.h, D, T, b.mu, c.output_size);
   if (r.rc == MIA_OK && hipGetLastError() != hipSuccess) return mia_fail(f->ctx, MIA_ERR_DEVICE, "flow: encoder launch failed");
@@ -382,7 +383,7 @@ void resnet(Run& r, const Resnet& rn, Bufs& b, const float* X, int Cin, int T, i
 }
 
 // BasicTransformerBlock (MatchaTransformer.swift:128-146) in place on x [2 T][C]
-void tblock(Run& r, const TBlock& t, Bufs& b, float* x, int T, int C, int H) {
+void tblock(Run& r, const TBlock& t, Bufs& b, float* x, int T, int C, int H, int chunk = 0) {
   const int M = 2 * T, inner = H * 64;
   float* h = b.c1;          // [M][C] scratch
   float* big = b.h1;        // [M][max(3 inner, 4 C)] scratch
@@ -390,7 +391,7 @@ void tblock(Run& r, const TBlock& t, Bufs& b, float* x, int T, int C, int H) {
   r.gemm(t.qkv, h, C, M, big, 3 * inner);
   AttnF32Args a;
   a.q = big; a.ldq = 3 * inner; a.k = big + inner; a.ldk = 3 * inner; a.v = big + 2 * inner; a.ldv = 3 * inner;
-  a.out = b.att2; a.ldo = inner; a.B = 2; a.T = T; a.H = H; a.scale = 0.125f;
+  a.out = b.att2; a.ldo = inner; a.B = 2; a.T = T; a.H = H; a.scale = 0.125f; a.chunk = chunk;
   r.attn(a);
   r.gemm(t.out, b.att2, inner, M, x, C, 0, x);
   r.ln(t.n3, x, h, M, C, 1e-5f);
@@ -501,16 +502,22 @@ int mia_flow_encode(mia_flow* f, const int32_t* token, int n_token, float* mu, i
   return MIA_OK;
 }
 
-int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
-                       int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, float* mel, int mem) {
+// finalize = 0 drops the encoder's last pre_lookahead_len * upsample_stride frames (CosyVoice2Model.swift:504-510); enc_chunk / dec_chunk > 0
+// switch the conformer encoder / the estimator's transformer blocks to their chunk-masked "streaming" attention
+static int flow_inference_impl(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
+                               int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, int finalize, int enc_chunk, int dec_chunk,
+                               float* mel, int* mel_frames, int mem) {
   if (!f) return MIA_ERR_MODEL_NOT_LOADED;
   mia_ctx* ctx = f->ctx;
   const mia_flow_config& c = f->cfg;
   MIA_CHECK_ARG(ctx, token && embedding && z && mel && n_token > 0 && n_prompt >= 0 && (n_prompt == 0 || prompt_token) &&
                          (mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE), "flow_inference: bad argument");
   const int S = n_timesteps > 0 ? n_timesteps : c.n_timesteps;
-  const int Tt = n_token + n_prompt, T = Tt * c.upsample_stride, M = c.output_size, C = c.dec_channels, H = c.dec_heads;
+  const int Tt = n_token + n_prompt, T_enc = Tt * c.upsample_stride, M = c.output_size, C = c.dec_channels, H = c.dec_heads;
+  const int trim = finalize ? 0 : c.pre_lookahead_len * c.upsample_stride;
+  const int T = T_enc > trim ? T_enc - trim : T_enc;       // (the reference trims only when something is left, :507)
   MIA_CHECK_ARG(ctx, Tt <= 4096 && S <= 1000, "flow_inference: at most 4096 tokens and 1000 steps");
+  MIA_CHECK_ARG(ctx, enc_chunk >= 0 && dec_chunk >= 0, "flow_inference: negative chunk size");
   MIA_CHECK_ARG(ctx, prompt_feat_len >= 0 && prompt_feat_len < T && (prompt_feat_len == 0 || prompt_feat), "flow_inference: prompt_feat_len must be in [0, %d)", T);
   MIA_HIP(ctx, hipSetDevice(ctx->device));
   Bufs b;
@@ -521,7 +528,7 @@ int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int
   MIA_HIP(ctx, hipMemcpyAsync(b.emb, embedding, (size_t)c.spk_embed_dim * 4, kind, s));
   MIA_HIP(ctx, hipMemcpyAsync(b.z, z, (size_t)T * M * 4, kind, s));
   if (prompt_feat_len) MIA_HIP(ctx, hipMemcpyAsync(b.pf, prompt_feat, (size_t)prompt_feat_len * M * 4, kind, s));
-  if (int rc = run_encoder(f, b, f->d_ids, Tt)) return rc;
+  if (int rc = run_encoder(f, b, f->d_ids, Tt, enc_chunk)) return rc;
   hipLaunchKernelGGL(flow_spks, dim3(1), dim3(256), 0, s, b.emb, f->spk.w, f->spk.b, b.spks, c.spk_embed_dim, M);
   const unsigned gTM = (unsigned)(((int64_t)T * M + 255) / 256);
   hipLaunchKernelGGL(flow_pack_inputs, dim3(gTM), dim3(256), 0, s, b.z, b.mu, b.spks, b.pf, b.hin, b.xs, T, M, prompt_feat_len);
@@ -562,19 +569,19 @@ int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int
     const float* tvec = b.tpr + (size_t)st * f->n_res * C;
     // down block
     resnet(r, f->down.rn, b, b.hin, IC, T, C, tvec, b.xr);
-    for (const TBlock& t : f->down.tb) tblock(r, t, b, b.xr, T, C, H);
+    for (const TBlock& t : f->down.tb) tblock(r, t, b, b.xr, T, C, H, dec_chunk);
     // skip -> right half of the up block's input; causal "downsample" conv (stride 1 for the single-level U-Net)
     MIA_HIP(ctx, hipMemcpy2DAsync(b.cat + C, (size_t)2 * C * 4, b.xr, (size_t)C * 4, (size_t)C * 4, M2, hipMemcpyDeviceToDevice, s));
     float* cur = b.xr2; float* nxt = b.xr;
     r.gemm(f->down_conv, b.xr, C, T, cur, C, 0, nullptr, 2, 2);
     for (const UBlock& mb : f->mid) {
       resnet(r, mb.rn, b, cur, C, T, C, tvec, nxt);
-      for (const TBlock& t : mb.tb) tblock(r, t, b, nxt, T, C, H);
+      for (const TBlock& t : mb.tb) tblock(r, t, b, nxt, T, C, H, dec_chunk);
       std::swap(cur, nxt);
     }
     MIA_HIP(ctx, hipMemcpy2DAsync(b.cat, (size_t)2 * C * 4, cur, (size_t)C * 4, (size_t)C * 4, M2, hipMemcpyDeviceToDevice, s));
     resnet(r, f->up.rn, b, b.cat, 2 * C, T, C, tvec, nxt);
-    for (const TBlock& t : f->up.tb) tblock(r, t, b, nxt, T, C, H);
+    for (const TBlock& t : f->up.tb) tblock(r, t, b, nxt, T, C, H, dec_chunk);
     r.gemm(f->up_conv2, nxt, C, T, cur, C, 0, nullptr, 2, 2);
     // final block + projection
     r.gemm(f->final_conv, cur, C, T, b.c1, C, 0, nullptr, 2, 2);
@@ -584,6 +591,7 @@ int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int
   }
   if (r.rc != MIA_OK) return r.rc;
   const int To = T - prompt_feat_len;
+  if (mel_frames) *mel_frames = To;
   float* dst = mem == MIA_MEM_DEVICE ? mel : b.out;
   hipLaunchKernelGGL(flow_emit, dim3((unsigned)(((int64_t)To * M + 255) / 256)), dim3(256), 0, s, b.xs, dst, T, M, prompt_feat_len);
   MIA_HIP(ctx, hipGetLastError());
@@ -592,6 +600,18 @@ int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int
     MIA_HIP(ctx, hipStreamSynchronize(s));
   }
   return MIA_OK;
+}
+
+int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
+                       int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, float* mel, int mem) {
+  return flow_inference_impl(f, token, n_token, prompt_token, n_prompt, prompt_feat, prompt_feat_len, embedding, z, n_timesteps, 1, 0, 0, mel, nullptr, mem);
+}
+
+int mia_flow_inference_streaming(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
+                                 int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, int finalize, int enc_static_chunk,
+                                 int dec_static_chunk, float* mel, int* mel_frames, int mem) {
+  return flow_inference_impl(f, token, n_token, prompt_token, n_prompt, prompt_feat, prompt_feat_len, embedding, z, n_timesteps, finalize ? 1 : 0,
+                             enc_static_chunk, dec_static_chunk, mel, mel_frames, mem);
 }
 
 }  // extern "C"

@@ -116,7 +116,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void lm_embed_norm(const int32_t* __restrict__ tokens, const uint16_t* __restrict__ emb, const uint16_t* __restrict__ gen_emb,
                                                      const float* __restrict__ embeds, const float* __restrict__ w,
                                                      float* __restrict__ x, uint16_t* __restrict__ h, const LmState* __restrict__ st, int D, float eps,
-                                                     const int2* __restrict__ rowmap, int max_ctx) {
+                                                     const int2* __restrict__ rowmap, int max_ctx, int emb_rows, int gen_rows) {
   __shared__ float sh[4];
   const int tid = threadIdx.x, nv = D >> 2;
   const int seq = rowmap ? rowmap[blockIdx.x].x : (int)blockIdx.x;         // prompt pass: row -> (sequence, position)
@@ -124,8 +124,11 @@ __global__ __launch_bounds__(256) void lm_embed_norm(const int32_t* __restrict__
   const int pos = rowmap ? rowmap[blockIdx.x].y : st->pos;
   x += (int64_t)blockIdx.x * D; h += (int64_t)blockIdx.x * D;
   const bool from_rows = pos < st->n_embeds;               // prompt given as embedding rows
-  const int tok = from_rows ? 0 : tokens[pos];
-  const uint16_t* e = ((st->n_embeds > 0 && gen_emb) ? gen_emb : emb) + (int64_t)tok * D;
+  const bool use_gen = st->n_embeds > 0 && gen_emb;
+  int tok = from_rows ? 0 : tokens[pos];
+  const int rows = use_gen ? gen_rows : emb_rows;
+  tok = tok < 0 ? 0 : (tok < rows ? tok : rows - 1);       // an id outside the table (a corrupted sampler output) must never become a wild address
+  const uint16_t* e = (use_gen ? gen_emb : emb) + (int64_t)tok * D;
   const float* er = embeds + (int64_t)pos * D;
   f32x4 v[LM_NV];
 #pragma unroll
@@ -970,7 +973,7 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
     return skinny_gemm_launch(a, mode, m->dtype, s);
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
-  LAUNCH_T(lm_embed_norm, dim3(nb), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps, (const int2*)nullptr, c.max_ctx);
+  LAUNCH_T(lm_embed_norm, dim3(nb), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, m->x, (uint16_t*)m->h, m->state, D, c.rms_eps, (const int2*)nullptr, c.max_ctx, c.vocab, m->gen_rows);
   const size_t layer_stride = (size_t)m->B_cap * c.n_kv_heads * c.max_ctx * dh;
   for (int l = 0; l < c.n_layers; ++l) {
     const LmLayer& L = m->layers[l];
@@ -1050,7 +1053,7 @@ int lm_prefill_rows(mia_lm* m, const std::vector<int2>& rows, const std::vector<
     // (pageable source: the copy is staged before the call returns, and the stream orders it behind the previous chunk's kernels)
     MIA_HIP(ctx, hipMemcpyAsync(rowmap, rows.data() + r0, (size_t)M * sizeof(int2), hipMemcpyHostToDevice, s));
     LAUNCH_T(lm_embed_norm, dim3(M), dim3(256), 0, m->tokens, (const uint16_t*)m->embed, (const uint16_t*)m->gen_embed, m->embeds, m->layers[0].in_norm, x, h,
-             m->state, D, c.rms_eps, (const int2*)rowmap, c.max_ctx);
+             m->state, D, c.rms_eps, (const int2*)rowmap, c.max_ctx, c.vocab, m->gen_rows);
     for (int l = 0; l < c.n_layers; ++l) {
       const LmLayer& L = m->layers[l];
       uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * layer_stride;
@@ -1319,6 +1322,10 @@ extern "C" int mia_lm_attach_q4(mia_lm* m, const mia_tensor_view* tensors, int n
   }
   if (!L.err.empty()) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "lm_attach_q4: %s", L.err.c_str());
   MIA_HIP(ctx, hipDeviceSynchronize());
+  // the packed kernel splits K in 128-input blocks: re-pick the cross-workgroup splits on that granule (the 16-bit step uses the same
+  // splits from here on, so switching between the two forms never changes a summation order)
+  auto split128 = [](int K, int want) { for (int sp = want; sp > 1; --sp) if (K % (128 * sp) == 0) return sp; return 1; };
+  m->S_qkv = split128(D, 4); m->S_o = split128(Nq, 4); m->S_down = split128(c.inter, 8);
   m->q4_scale_dtype = sdt;
   m->q4 = true;
   m->graph_mode = -1;          // the captured step holds the 16-bit launches: re-capture

@@ -50,6 +50,7 @@ extern "C" void mia_destroy(mia_ctx* ctx) {
   }
   for (void* p : ctx->table_allocs) (void)hipFree(p);
   if (ctx->s3gen_mel) free(ctx->s3gen_mel);
+  mia_resampler_free(ctx);
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->ws) (void)hipFree(ctx->ws);

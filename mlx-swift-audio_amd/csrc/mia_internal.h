@@ -10,6 +10,8 @@
 
 #include "../../include/mia.h"
 
+struct mia_resampler_cache;
+
 struct mia_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -31,6 +33,7 @@ struct mia_ctx {
   std::vector<MelTables> mel_tables;
   std::vector<void*> table_allocs;   // other cached device tables (freed at destroy), e.g. the 24 kHz 80-mel front end
   void* s3gen_mel = nullptr;         // S3GenMelTables* (mel_s3gen.hip), lives in table_allocs' lifetime
+  mia_resampler_cache* resampler = nullptr;   // per-ratio polyphase filters of mia_resample_sinc (resample.hip); device tables in table_allocs
   // optional HIP-event profiling of kernel classes (mia_profile_*): bench.py's roofline figures come from here
   bool prof_on = false;
   struct ProfRec { int cls; hipEvent_t start, stop; double work; };
@@ -79,3 +82,5 @@ void* mia_workspace(mia_ctx* ctx, size_t bytes);
 inline size_t mia_dtype_size(int dt) { return dt == MIA_F32 ? 4 : 2; }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+void mia_resampler_free(mia_ctx* ctx);   // resample.hip

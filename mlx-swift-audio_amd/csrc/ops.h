@@ -25,6 +25,8 @@ struct AttnF32Args {
   float* out = nullptr; int64_t ldo = 0;
   int B = 1, T = 0, H = 0;
   float scale = 0.125f;
+  int chunk = 0;      // > 0: block-causal "streaming" mask, query i sees keys j < (i / chunk + 1) * chunk (subsequentChunkMask,
+                      // Codec/S3Gen/Transformer/UpsampleConformerEncoder.swift:124-129); 0 = full attention
 };
 const char* mia_attn_f32_check(const AttnF32Args& a);
 int mia_attn_f32_launch(const AttnF32Args& a, hipStream_t s);

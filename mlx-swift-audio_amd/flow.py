@@ -71,6 +71,32 @@ class FlowModule:
         self.ctx.check(self.ctx.lib.mia_flow_encode(self.h, t.ctypes.data, t.shape[0], mu.ctypes.data, _lib.MEM_HOST))
         return mu
 
+    def inference_streaming(self, token, prompt_token, prompt_feat, embedding, z, n_timesteps: int | None = None, finalize: bool = True,
+                            enc_static_chunk: int = 0, dec_static_chunk: int = 0) -> np.ndarray:
+        """inference(...) with the modules' chunked-synthesis switches (mia_flow_inference_streaming): finalize = False trims the encoder's
+        look-ahead frames (z is then [80, T - pre_lookahead_len * upsample_stride]); *_static_chunk > 0 = streaming attention masks."""
+        lib = self.ctx.lib
+        lib.mia_flow_inference_streaming.restype = C.c_int
+        lib.mia_flow_inference_streaming.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        t = np.ascontiguousarray(token, np.int32)
+        pt = np.ascontiguousarray(prompt_token, np.int32)
+        pf = np.ascontiguousarray(prompt_feat, np.float32).reshape(-1, self.cfg.output_size)
+        e = np.ascontiguousarray(embedding, np.float32).reshape(-1)
+        zz = np.ascontiguousarray(z, np.float32)
+        T = (t.shape[0] + pt.shape[0]) * self.cfg.upsample_stride
+        trim = 0 if finalize else self.cfg.pre_lookahead_len * self.cfg.upsample_stride
+        T = T - trim if T > trim else T
+        if zz.shape != (self.cfg.output_size, T) or e.shape[0] != self.cfg.spk_embed_dim:
+            raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, f"flow: z must be [{self.cfg.output_size}, {T}] and embedding [{self.cfg.spk_embed_dim}]")
+        mel = np.empty((self.cfg.output_size, T - pf.shape[0]), np.float32)
+        nf = C.c_int(0)
+        self.ctx.check(lib.mia_flow_inference_streaming(self.h, t.ctypes.data, t.shape[0], pt.ctypes.data if pt.size else None, pt.shape[0],
+                                                        pf.ctypes.data if pf.size else None, pf.shape[0], e.ctypes.data, zz.ctypes.data, n_timesteps or 0,
+                                                        1 if finalize else 0, enc_static_chunk, dec_static_chunk, mel.ctypes.data, C.byref(nf), _lib.MEM_HOST))
+        assert nf.value == mel.shape[1]
+        return mel
+
     def inference(self, token, prompt_token, prompt_feat, embedding, z, n_timesteps: int | None = None) -> np.ndarray:
         """token [n], prompt_token [m] (may be empty), prompt_feat [m1, 80], embedding [spk_embed_dim], z [80, 2 (n + m)] -> mel [80, 2 (n + m) - m1]"""
         t = np.ascontiguousarray(token, np.int32)

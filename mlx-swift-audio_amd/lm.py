@@ -73,6 +73,36 @@ class CausalLM:
             raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, ctx.lib.mia_last_error(ctx.h).decode())
         return CausalLM(ctx, h, cfg)
 
+    def attach_q4(self, packed: dict[str, np.ndarray], group_size: int = 64) -> None:
+        """mia_lm_attach_q4: `packed` holds every step Linear as the checkpoint stores it -- `<name>.weight` uint32 codes,
+        `<name>.scales` / `<name>.biases` float16 (or uint16 arrays tagged .st_dtype == "BF16", as checkpoint.read_safetensors returns
+        bf16 payloads).  The handle must have been loaded from the de-quantised tensors of the same checkpoint."""
+        lib = self.ctx.lib
+        lib.mia_lm_attach_q4.restype = C.c_int
+        lib.mia_lm_attach_q4.argtypes = [C.c_void_p, C.POINTER(_TensorView), C.c_int, C.c_int]
+        views = (_TensorView * len(packed))()
+        keep = []
+        for i, (name, arr) in enumerate(packed.items()):
+            a = np.ascontiguousarray(arr)
+            if a.dtype == np.uint32:
+                dt = _lib.U32
+            elif a.dtype == np.float16:
+                dt = _lib.F16
+            elif a.dtype == np.uint16 and getattr(arr, "st_dtype", "BF16") == "BF16":
+                dt = _lib.BF16
+            else:
+                raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, f"attach_q4: '{name}' must be uint32 codes or 16-bit scales / biases (got {a.dtype})")
+            keep.append(a)
+            shp = (C.c_int64 * 4)(*(list(a.shape) + [0] * (4 - a.ndim)))
+            views[i] = _TensorView(name.encode(), dt, a.ndim, shp, a.ctypes.data)
+        self.ctx.check(lib.mia_lm_attach_q4(self.h, views, len(packed), group_size))
+
+    def use_q4(self, on: bool) -> None:
+        lib = self.ctx.lib
+        lib.mia_lm_use_q4.restype = C.c_int
+        lib.mia_lm_use_q4.argtypes = [C.c_void_p, C.c_int]
+        self.ctx.check(lib.mia_lm_use_q4(self.h, 1 if on else 0))
+
     def close(self):
         if self.h and getattr(self.ctx, 'h', None):
             self.ctx.lib.mia_lm_free(self.h)

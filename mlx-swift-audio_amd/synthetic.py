@@ -320,6 +320,8 @@ LM_CONFIGS = {
     "orpheus-3b": LMConfig(156940, 3072, 8192, 28, 24, 8, 128, 2048),
     # Qwen2Config defaults (Qwen2LM.swift:15-43): the CosyVoice2-0.5B backbone
     "qwen2-0.5b": LMConfig(151936, 896, 4864, 24, 14, 2, 64, 2048, 1e-6, 1e6, False, 1.0, 1.0, 4.0, 8192, True, True),
+    # mid-size shape for the packed-q4 step: K = 1024 / 2048 give several 128-input blocks per wave, 4-wave workgroups and cross-workgroup splits
+    "llama-q4mid": LMConfig(3000, 1024, 2048, 2, 8, 2, 128, 256),
     "llama-micro": LMConfig(3000, 256, 512, 2, 4, 2, 64, 256),
     "llama-micro128": LMConfig(3000, 256, 512, 2, 2, 1, 128, 256),
     "qwen-micro": LMConfig(3000, 128, 384, 2, 2, 1, 64, 256, 1e-6, 1e6, False, 1.0, 1.0, 4.0, 8192, True, True),

@@ -271,3 +271,98 @@ def test_ras_top_k_with_exact_ties(ctx, n_tied):
             want.append(t)
     assert got == want
     model.close()
+
+
+def _quantized_checkpoint(cfg, seed, scale_dtype=np.float16):
+    """A q4 / group-64 checkpoint in the MLX layout plus its de-quantised tensors: every step Linear (and the tied embedding) of a seeded
+    random-init model is quantised with the test-side restatement of mx.quantize (oracle/quant.py), scales / biases rounded to the
+    16-bit type a checkpoint stores them in."""
+    from oracle import quant as OQ
+    w = S.lm_weights(cfg, seed=seed)
+    packed, dense = {}, dict(w)
+    names = ["model.embed_tokens"] if cfg.tie_embeddings else ["lm_head"]
+    for l in range(cfg.n_layers):
+        p = f"model.layers.{l}"
+        names += [p + ".self_attn." + n + "_proj" for n in "qkvo"] + [p + ".mlp." + n + "_proj" for n in ("gate", "up", "down")]
+    for n in names:
+        pk, sc, bi = OQ.quantize_affine(w[n + ".weight"], 64, 4)
+        sc, bi = sc.astype(scale_dtype), bi.astype(scale_dtype)
+        packed[n + ".weight"], packed[n + ".scales"], packed[n + ".biases"] = pk, sc, bi
+        dense[n + ".weight"] = OQ.dequantize_affine(pk, sc.astype(np.float32), bi.astype(np.float32), 64, 4)
+    return packed, dense
+
+
+@pytest.mark.parametrize("cfg_name,dtype_name", [("llama-micro128", "bf16"), ("qwen-micro", "f16")])
+def test_q4_step_equals_expanded_checkpoint(ctx, cfg_name, dtype_name):
+    """Packed MLX-affine 4-bit step (mia_lm_attach_q4: 4.5 bits per weight streamed, expanded in registers) vs the SAME checkpoint expanded
+    to 16 bit at load: the expansion is value for value the same and the K order of every accumulation is the dense kernel's, so the
+    logits must be IDENTICAL, step after step, for one sequence and for a batch; and both must sit on the fp32 oracle of the
+    de-quantised weights within the usual 16-bit tolerance."""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    cfg = S.LM_CONFIGS[cfg_name]
+    packed, dense = _quantized_checkpoint(cfg, seed=11)
+    model = HL.CausalLM.load(ctx, cfg, dense, _dt(dtype_name))
+    ids = np.random.default_rng(2).integers(0, cfg.vocab, 9).tolist()
+    model.attach_q4(packed)
+    model.use_q4(False)                             # the 16-bit weights of the same handle (same cross-workgroup splits)
+    ref_steps = []
+    for t in ids:                                   # token by token: every call is one step graph launch
+        ref_steps.append(model.forward([t]).copy())
+    model.use_q4(True)
+    model.reset()
+    for t, want in zip(ids, ref_steps):
+        got = model.forward([t])
+        assert np.array_equal(got, want), np.abs(got - want).max()
+    ora = OL.LMOracle(cfg, {k: S.round_array(v, dtype_name) if v.ndim == 2 else v for k, v in dense.items()})
+    ref = ora.forward(ids).numpy()[-1]
+    assert np.abs(ref_steps[-1] - ref).max() <= 0.08 * ref.std()
+    # sampled generation, packed vs 16-bit: same ids
+    u = np.random.default_rng(4).random(20).astype(np.float32)
+    kw = dict(temperature=0.7, top_p=0.9, rep_penalty=1.2, rep_window=16, max_new_tokens=20, stop_ids=(cfg.vocab - 1,))
+    a = model.generate(ids, u, **kw)
+    model.use_q4(False)
+    b = model.generate(ids, u, **kw)
+    assert a == b
+    model.use_q4(True)
+    model.set_batch(4)
+    prompts = [ids, ids[:3], ids[2:], ids[::-1]]
+    ub = np.random.default_rng(5).random((4, 12)).astype(np.float32)
+    kw["max_new_tokens"] = 12
+    qa = model.generate_batch(prompts, ub, **kw)
+    model.use_q4(False)
+    assert model.generate_batch(prompts, ub, **kw) == qa
+    with pytest.raises(m.MiaError):
+        model.attach_q4({k: v for k, v in packed.items() if "q_proj" not in k})     # an incomplete set is rejected
+    model.close()
+
+
+def test_q4_step_mid_size_batch_32(ctx):
+    """The packed step at a shape that exercises what the micro models cannot: several 128-input blocks per wave (the 3-deep register ring),
+    4-wave workgroups, cross-workgroup K splits, the 4-tile head and a FULL 32-row batch (both 16-row MFMA halves).  32 sequences decoded
+    side by side must give, sequence by sequence, the ids of the 16-bit step on the same de-quantised weights."""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    cfg = S.LM_CONFIGS["llama-q4mid"]
+    packed, dense = _quantized_checkpoint(cfg, seed=21)
+    model = HL.CausalLM.load(ctx, cfg, dense, m.BF16)
+    model.attach_q4(packed)
+    rng = np.random.default_rng(6)
+    ids = rng.integers(0, cfg.vocab, 12).tolist()
+    model.use_q4(False)
+    want = [model.forward([t]).copy() for t in ids]
+    model.use_q4(True)
+    model.reset()
+    for t, w_ in zip(ids, want):
+        got = model.forward([t])
+        assert np.isfinite(got).all() and np.array_equal(got, w_), np.abs(got - w_).max()
+    model.set_batch(32)
+    prompts = [rng.integers(0, cfg.vocab, int(n)).tolist() for n in rng.integers(1, 20, 32)]
+    ub = rng.random((32, 16)).astype(np.float32)
+    kw = dict(temperature=0.8, top_p=0.9, rep_penalty=1.1, rep_window=8, max_new_tokens=16, stop_ids=(cfg.vocab - 1,))
+    q = model.generate_batch(prompts, ub, **kw)
+    model.use_q4(False)
+    d = model.generate_batch(prompts, ub, **kw)
+    assert q == d
+    assert all(0 <= t < cfg.vocab for seq in q for t in seq)
+    model.close()

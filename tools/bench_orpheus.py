@@ -23,8 +23,23 @@ ctx = m.Context(0)
 t0 = time.time()
 w = S.lm_weights(cfg, seed=0, dtype=np.float16)
 print(f"[orpheus] weights generated in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
+q4 = os.environ.get("MIA_BENCH_Q4") == "1"       # MLX-affine 4-bit step weights (the reference's default Orpheus checkpoint is q4, group 64)
+if q4:
+    from mlx_swift_audio_amd import checkpoint as CK
+    t0 = time.time()
+    packed, names = {}, (["model.embed_tokens"] if cfg.tie_embeddings else ["lm_head"])
+    for l in range(cfg.n_layers):
+        names += [f"model.layers.{l}.self_attn.{n}_proj" for n in "qkvo"] + [f"model.layers.{l}.mlp.{n}_proj" for n in ("gate", "up", "down")]
+    for n in names:
+        pk, sc, bi = CK.quantize_affine(w[n + ".weight"])
+        packed[n + ".weight"], packed[n + ".scales"], packed[n + ".biases"] = pk, sc, bi
+        w[n + ".weight"] = CK.dequantize_affine(ctx, pk, sc, bi).astype(np.float16)      # the expanded checkpoint (prompt pass)
+    print(f"[orpheus] quantised + expanded in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
 model = HL.CausalLM.load(ctx, cfg, w, m.BF16)
 del w
+if q4:
+    model.attach_q4(packed)
+    del packed
 scfg = S.SNAC_CONFIGS["snac_24khz"]
 snac = HC.SNACDecoder.load(ctx, scfg, S.snac_weights(scfg, 0))
 rng = np.random.default_rng(0)
@@ -43,7 +58,7 @@ steps = len(gen) - 1                     # decode steps after the one the prompt
 dt_dec = dt - d_prompt
 params = sum(int(np.prod(s)) for s in [(cfg.vocab, cfg.hidden)]) + cfg.n_layers * ((cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim * cfg.hidden +
                                                                               cfg.hidden * cfg.n_heads * cfg.head_dim + 3 * cfg.inter * cfg.hidden)
-bytes_per_tok = 2.0 * params
+bytes_per_tok = 2.0 * params if not q4 else params * (0.5 + 4.0 / 64)     # 4 bits + (scale, bias) 2 x 16 bit per 64 weights
 n = len(gen) // 7
 codes = [rng.integers(0, 4096, n).tolist(), rng.integers(0, 4096, 2 * n).tolist(), rng.integers(0, 4096, 4 * n).tolist()]
 noise = rng.standard_normal(snac.noise_len(4 * n)).astype(np.float32)
@@ -67,7 +82,7 @@ if batch > 1:
     batch_res = {"sequences": batch, "seconds": round(db, 4), "tokens_per_s": round(ntok / db, 1), "ms_per_step": round(db / n_new * 1e3, 3),
                  "audio_seconds_per_second_lm_only": round((ntok / 7 * 2048 / 24000.0) / db, 2)}
     model.set_batch(1)
-print(json.dumps({"batch": batch_res, "model": name, "prompt_tokens": n_prompt, "generated_tokens": len(gen), "seconds": round(dt, 4),
+print(json.dumps({"batch": batch_res, "model": name, "weights": "mlx-affine q4 g64 (packed step)" if q4 else "bf16", "prompt_tokens": n_prompt, "generated_tokens": len(gen), "seconds": round(dt, 4),
                   "prompt_pass_plus_first_step_ms": round(d_prompt * 1e3, 2),
                   "tokens_per_s": round(steps / dt_dec, 1), "ms_per_token": round(dt_dec / steps * 1e3, 3),
                   "weight_GB_per_token": round(bytes_per_tok / 1e9, 3), "hbm_GBs": round(bytes_per_tok * steps / dt_dec / 1e9, 1),
