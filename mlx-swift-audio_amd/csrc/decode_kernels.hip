@@ -308,7 +308,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct Q4Frag { const uint32_t* wfrag; const uint16_t* sbfrag; int sdt; };
 
-template <typename T, int MODE, int NT, int NW>
+// M16: at most 16 rows (single-sequence decode, small batches): the second 16-row MFMA half and its activation loads are skipped
+template <typename T, int MODE, int NT, int NW, bool M16>
 __global__ __launch_bounds__(64 * NW) void skinny_gemm_q4(SkinnyArgs a, Q4Frag q) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_q4(SkinnyArgs a, Q4Frag q
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       b.a0[st] = *reinterpret_cast<const s16x8*>(ap0 + (int64_t)blk * 128 + 32 * st);
-      b.a1[st] = *reinterpret_cast<const s16x8*>(ap1 + (int64_t)blk * 128 + 32 * st);
+      if (!M16) b.a1[st] = *reinterpret_cast<const s16x8*>(ap1 + (int64_t)blk * 128 + 32 * st);
     }
   };
   auto cvt = [&](uint32_t h16) -> float { return q.sdt == MIA_F16 ? F16::to_f32((uint16_t)h16) : BF16::to_f32((uint16_t)h16); };
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_q4(SkinnyArgs a, Q4Frag q
         }
         const s16x8 fw = __builtin_bit_cast(s16x8, (u32x4){pk[0], pk[1], pk[2], pk[3]});
         acc[t][0] = T::mfma16(fw, b.a0[st], acc[t][0]);
-        acc[t][1] = T::mfma16(fw, b.a1[st], acc[t][1]);
+        if (!M16) acc[t][1] = T::mfma16(fw, b.a1[st], acc[t][1]);
       }
     }
   };
@@ -992,27 +993,33 @@ int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) 
 }
 
 
-template <typename T>
-static void skinny_q4_launch_t(const SkinnyArgs& a, const Q4Frag& q, int mode, hipStream_t s) {
+template <typename T, bool M16>
+static void skinny_q4_launch_m(const SkinnyArgs& a, const Q4Frag& q, int mode, hipStream_t s) {
   const int tiles = (a.N + 15) / 16, nblk = a.K / 128;
   const bool nw4 = nblk % (4 * a.S) == 0;
-  if (mode == SK_OUTF32) {   // vocabulary-wide head: 4 tiles per wave (activation fragments are reused 4 times)
-    dim3 grid((tiles + 3) / 4, a.S, (a.M + 31) / 32);
-    hipLaunchKernelGGL((skinny_gemm_q4<T, SK_OUTF32, 4, 1>), grid, dim3(64), 0, s, a, q);
-    return;
-  }
-  dim3 grid(tiles, a.S, (a.M + 31) / 32);
-#define Q4_LAUNCH(MODE_)                                                                                   \
-  do {                                                                                                     \
-    if (nw4) hipLaunchKernelGGL((skinny_gemm_q4<T, MODE_, 1, 4>), grid, dim3(256), 0, s, a, q);             \
-    else hipLaunchKernelGGL((skinny_gemm_q4<T, MODE_, 1, 1>), grid, dim3(64), 0, s, a, q);                  \
+  const int zb = (a.M + 31) / 32;
+  // 4 tiles per wave whenever that still leaves every CU a workgroup: the activation fragments (the larger share of a wave's loads:
+  // 16 bits x 32 rows against 4 bits x 16 rows per tile) are then reused four times
+  const bool nt4 = mode == SK_OUTF32 || (int64_t)((tiles + 3) / 4) * a.S * zb >= 256;
+#define Q4_GO(MODE_, NT_, NW_) hipLaunchKernelGGL((skinny_gemm_q4<T, MODE_, NT_, NW_, M16>), dim3((tiles + NT_ - 1) / NT_, a.S, zb), dim3(64 * NW_), 0, s, a, q)
+#define Q4_LAUNCH(MODE_)                                                        \
+  do {                                                                          \
+    if (nt4) { if (nw4) Q4_GO(MODE_, 4, 4); else Q4_GO(MODE_, 4, 1); }           \
+    else { if (nw4) Q4_GO(MODE_, 1, 4); else Q4_GO(MODE_, 1, 1); }               \
   } while (0)
   switch (mode) {
+    case SK_OUTF32: Q4_GO(SK_OUTF32, 4, 1); break;      // vocabulary-wide head
     case SK_OUT16: Q4_LAUNCH(SK_OUT16); break;
     case SK_SWIGLU: Q4_LAUNCH(SK_SWIGLU); break;
     default: Q4_LAUNCH(SK_PARTIAL); break;
   }
 #undef Q4_LAUNCH
+#undef Q4_GO
+}
+
+template <typename T>
+static void skinny_q4_launch_t(const SkinnyArgs& a, const Q4Frag& q, int mode, hipStream_t s) {
+  if (a.M <= 16) skinny_q4_launch_m<T, true>(a, q, mode, s); else skinny_q4_launch_m<T, false>(a, q, mode, s);
 }
 
 // 4-bit form of skinny_gemm_launch: a.W is ignored, the weights come from the fragment-ordered arrays (see skinny_gemm_q4)

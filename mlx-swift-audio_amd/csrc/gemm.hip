@@ -653,6 +653,50 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
       return;
     }
   }
+  if constexpr (OUT_F32 && EPI == MIA_EPI_STD) {
+    // fp32 output (+ fp32 residual): the direct form reads and writes 64-B row pieces, 16 rows per instruction.  Through the wave's 16 KB of
+    // LDS (two halves of 64 rows x 256 B, 16-B chunk XOR (row & 15)) every load / store instruction covers 4 whole 256-B row segments,
+    // and the residual is fetched with the same coalesced shape.
+    const bool rows32 = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (((uintptr_t)g.C) & 15) == 0 && (g.strideC & 3) == 0 &&
+                        (g.R == nullptr || ((g.ldr & 3) == 0 && (((uintptr_t)g.R) & 15) == 0 && (g.strideR & 3) == 0));
+    if (rows32) {
+      char* reg = lds + wave * 16384;
+      float* cb = reinterpret_cast<float*>(g.C) + (int64_t)bz * g.strideC;
+      const float* rb = g.R ? g.R + (int64_t)bz * g.strideR : nullptr;
+      const int c16 = lane & 15;
+      const int n = n0 + wc * 64 + c16 * 4;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int row = mt * 16 + e_m;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(acc[mh * 4 + mt][nt][j] + bias4[nt][j], g.act);
+            const int wc16 = nt * 4 + (lane >> 4);
+            *reinterpret_cast<f32x4*>(reg + row * 256 + ((wc16 ^ (row & 15)) << 4)) = v;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = 4 * i + (lane >> 4);
+          f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 256 + ((c16 ^ (row & 15)) << 4));
+          const int m = m0 + wr * 128 + mh * 64 + row;
+          if (m < g.M && n < g.N) {
+            if (rb) {
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(rb + (int64_t)m * g.ldr + n);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] += rv[j];
+            }
+            *reinterpret_cast<f32x4*>(cb + (int64_t)m * g.ldc + n) = v;
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int m = m0 + wr * 128 + mt * 16 + e_m;
