@@ -7,8 +7,12 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_committed_bench_line_has_every_contract_field():
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_turbo_b32.json")).read().strip().splitlines()[-1]
+import pytest
+
+
+@pytest.mark.parametrize("name", ["r01_bench_turbo_b32.json", "r02_bench_turbo_b32.json"])
+def test_committed_bench_line_has_every_contract_field(name):
+    line = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
@@ -22,6 +26,12 @@ def test_committed_bench_line_has_every_contract_field():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or 0.9 * r["bytes_per_launch"] <= r["traffic"] <= 1.2 * r["bytes_per_launch"]   # PMC bytes ~ algorithmic bytes
+    if name.startswith("r02"):
+        # the roofline's launch time comes from strictly serial passes in the same process, reported beside the pipelined `value`
+        e = r["execution"]
+        assert e["replicas"] == 1 and e["value"] <= d["value"] and abs(e["value"] - 32 * 30.0 / (e["ms_per_step"] * 1e-3)) <= 0.01 * e["value"]
+        assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 0.01 * r["achieved"]
+        assert d["config"]["exchange"] == "none" and "config0" in d and d["config0"]["gpu"]["generated_tokens"] > 0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
