@@ -293,6 +293,53 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
   skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
 }
 
+// The same GEMM for a SHORT K-slice per wave (exactly NSTEP K-steps of 32, host-checked: K == S * NW * 32 * NSTEP): every operand
+// load of the wave is issued before the first MFMA, so the kernel pays ONE memory round trip (the ring above pays one per refill:
+// two to three on a 160- or 320-wide slice, ~1.5 us each on a step that is a chain of such kernels).  Weights are read once per
+// step and never again before 1.3 GB of other traffic has passed: non-temporal loads keep them from displacing the activations in
+// L2 / MALL.  Same K order per wave and same wave-order reduction as dec_skinny_gemm: results are bit-identical to it.
+template <typename T, int MODE, int NT, int NSTEP, int NW>
+__global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * (16 * NT);
+  const int split = blockIdx.y;
+  const int m0 = blockIdx.z * 32;
+  constexpr int Kc = 32 * NSTEP;
+  const int kbeg = (split * NW + wave) * Kc;
+  const int r = lane & 15, c = lane >> 4;
+  const uint16_t* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int wn = n0 + 16 * t + r; wn = wn < a.N ? wn : a.N - 1;
+    wp[t] = a.W + (int64_t)wn * a.K + kbeg + 8 * c;
+  }
+  int am0 = m0 + r; am0 = am0 < a.M ? am0 : a.M - 1;
+  int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
+  const uint16_t* ap0 = a.A + (int64_t)am0 * a.lda + kbeg + 8 * c;
+  const uint16_t* ap1 = a.A + (int64_t)am1 * a.lda + kbeg + 8 * c;
+  s16x8 fw[NSTEP][NT], fa0[NSTEP], fa1[NSTEP];
+#pragma unroll
+  for (int u = 0; u < NSTEP; ++u) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) fw[u][n] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp[n] + 32 * u));
+    fa0[u] = *reinterpret_cast<const s16x8*>(ap0 + 32 * u);
+    fa1[u] = *reinterpret_cast<const s16x8*>(ap1 + 32 * u);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep every load ahead of the first MFMA (the scheduler would otherwise trade them for registers)
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int u = 0; u < NSTEP; ++u)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      acc[n][0] = T::mfma16(fw[u][n], fa0[u], acc[n][0]);
+      acc[n][1] = T::mfma16(fw[u][n], fa1[u], acc[n][1]);
+    }
+  if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
+  skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The same skinny GEMM on MLX-affine 4-bit weights (group 64: w = scale * code + bias), de-quantised IN REGISTERS: the step streams
 // 4.5 bits per weight from HBM instead of 16 (Orpheus-3B: 1.9 GB instead of 6.6 GB per token).  Replaces MLX's quantizedMatmul on the
@@ -395,7 +442,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_q4(SkinnyArgs a, Q4Frag q
 // ------------------------------------------------------------------------------------------------
 constexpr int DEC_MAX_KEYS = 1536;
 
-template <typename T>
+// U = independent 1 KB loads a wave keeps in flight per trip (8 U keys); NTL = non-temporal K/V loads (the cross K/V of a step is
+// 1 GB read once: keep it from displacing the step's weights and activations in L2 / MALL)
+template <typename T, int U, bool NTL>
 __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
                                                      const uint16_t* __restrict__ vc, uint16_t* __restrict__ out,
                                                      const int32_t* __restrict__ pos_arr, int fixed_keys, int cap_keys, int H,
@@ -417,26 +466,46 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = T::to_f32((uint16_t)qv[j]);
   }
-  // ---- scores: each wave owns 32 consecutive keys per trip (4 independent 1 KB loads in flight)
-  for (int k0 = wave * 32; k0 < nk; k0 += 128) {
-    s16x8 kv[4];
+  auto ld = [](const uint16_t* p) -> s16x8 {
+    if (NTL) return __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(p));
+    return *reinterpret_cast<const s16x8*>(p);
+  };
+  auto load_trip = [&](s16x8 (&dst)[U], const uint16_t* base, int k0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       int key = k0 + 8 * u + g; key = key < nk ? key : nk - 1;
-      kv[u] = *reinterpret_cast<const s16x8*>(kb + (int64_t)key * 64 + c * 8);
+      dst[u] = ld(base + (int64_t)key * 64 + c * 8);
     }
+  };
+  constexpr int TRIP = 32 * U;   // keys per workgroup trip; a wave owns 8 U consecutive keys of it
+  // ---- scores: the next trip's U independent 1 KB loads are issued before the current trip's dot products (U .. 2U loads in flight)
+  {
+    int k0 = wave * (8 * U);
+    s16x8 kv[U], kn[U];
+    if (k0 < nk) load_trip(kv, kb, k0);
+    for (; k0 < nk; k0 += TRIP) {
+      const bool more = k0 + TRIP < nk;
+      if (more) load_trip(kn, kb, k0 + TRIP);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float dot = 0.f;
+      for (int u = 0; u < U; ++u) {
+        float dot = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dot += qf[j] * T::to_f32((uint16_t)kv[u][j]);
-      dot += __shfl_xor(dot, 1, 64);
-      dot += __shfl_xor(dot, 2, 64);
-      dot += __shfl_xor(dot, 4, 64);
-      const int key = k0 + 8 * u + g;
-      if (c == 0 && key < nk) sc[key] = dot * scale;
+        for (int j = 0; j < 8; ++j) dot += qf[j] * T::to_f32((uint16_t)kv[u][j]);
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+        const int key = k0 + 8 * u + g;
+        if (c == 0 && key < nk) sc[key] = dot * scale;
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) kv[u] = kn[u];
+      }
     }
   }
+  // the first V trip does not depend on the probabilities: its loads fly during the softmax
+  s16x8 vv[U], vn[U];
+  if (wave * (8 * U) < nk) load_trip(vv, vb, wave * (8 * U));
   __syncthreads();
   // word-timestamp alignment (WhisperTiming.swift:605-640): keep the pre-softmax scores of the alignment heads, row = decoder position
   if (qk_out && head_slot[h] >= 0) {
@@ -460,20 +529,23 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int k0 = wave * 32; k0 < nk; k0 += 128) {
-    s16x8 vv[4];
-    float pw[4];
+  for (int k0 = wave * (8 * U); k0 < nk; k0 += TRIP) {
+    const bool more = k0 + TRIP < nk;
+    if (more) load_trip(vn, vb, k0 + TRIP);
+    float pw[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int key = k0 + 8 * u + g;
-      const int kc2 = key < nk ? key : nk - 1;
-      vv[u] = *reinterpret_cast<const s16x8*>(vb + (int64_t)kc2 * 64 + c * 8);
-      pw[u] = key < nk ? sc[kc2] : 0.f;
+      pw[u] = key < nk ? sc[key] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += pw[u] * T::to_f32((uint16_t)vv[u][j]);
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) vv[u] = vn[u];
+    }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -961,8 +1033,38 @@ int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln
   return 0;
 }
 
+// short-K-slice form (dec_skinny_flat): K per split = NW x 32 x NSTEP for one of the instantiated NSTEP
+// `free_partition`: the caller accepts any split of K over waves (the Whisper step).  The LM step does not: its packed-weight twin
+// (skinny_gemm_q4) must sum in the same order, so there the flat form is taken only where it keeps the ring kernel's 4-wave split.
+template <typename T, int MODE, int NT>
+static bool skinny_flat_try(const SkinnyArgs& a, bool free_partition, hipStream_t s) {
+  if (std::getenv("MIA_SKINNY_NO_FLAT")) return false;   // A/B switch for tools/ (the ring kernel gives bit-identical results)
+  const int tiles = (a.N + 16 * NT - 1) / (16 * NT), zb = (a.M + 31) / 32;
+  const int64_t wgs = (int64_t)tiles * a.S * zb;
+  if (a.K % (32 * a.S) != 0 || wgs > 4096) return false;
+  const int per_split = a.K / a.S;
+  if (!free_partition && !(MODE != SK_OUTF32 && wgs <= 1024 && a.K % (128 * a.S) == 0 && per_split >= 512)) return false;
+  const dim3 grid(tiles, a.S, zb);
+#define FLAT(NW_, NSTEP_)                                                                                             \
+  if (per_split == NW_ * 32 * NSTEP_) {                                                                               \
+    hipLaunchKernelGGL((dec_skinny_flat<T, MODE, NT, NSTEP_, NW_>), grid, dim3(64 * NW_), 0, s, a);                    \
+    return true;                                                                                                      \
+  }
+  if (wgs <= 128 && free_partition) { FLAT(8, 5) }   // a grid that leaves half the CUs empty: twice the waves, half the slice
+  FLAT(4, 10) FLAT(4, 5) FLAT(4, 8) FLAT(4, 6) FLAT(4, 4) FLAT(4, 3)
+#undef FLAT
+  return false;
+}
+
 template <typename T>
-static void skinny_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
+static void skinny_launch_t(const SkinnyArgs& a, int mode, bool fp, hipStream_t s) {
+  switch (mode) {
+    case SK_OUTF32: break;   // the vocabulary-wide GEMM is bandwidth-bound: the ring kernel below (measured: flat forms are 11-14 us slower)
+    case SK_OUT16: if (skinny_flat_try<T, SK_OUT16, 1>(a, fp, s)) return; break;
+    case SK_PARTIAL: if (skinny_flat_try<T, SK_PARTIAL, 1>(a, fp, s)) return; break;
+    case SK_SWIGLU: if (skinny_flat_try<T, SK_SWIGLU, 1>(a, fp, s)) return; break;
+    default: if (skinny_flat_try<T, SK_QKV, 1>(a, fp, s)) return; break;
+  }
   if (mode == SK_OUTF32) {   // the vocabulary-wide logits GEMM: 64 columns per wave
     dim3 grid((a.N + 63) / 64, a.S, (a.M + 31) / 32);
     hipLaunchKernelGGL((dec_skinny_gemm<T, SK_OUTF32, 4, 2, 1>), grid, dim3(64), 0, s, a);
@@ -985,12 +1087,13 @@ static void skinny_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
 #undef SK_LAUNCH
 }
 
-int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) {
+static int skinny_gemm_launch_p(const SkinnyArgs& a, int mode, int dtype, bool free_partition, hipStream_t s) {
   if (a.K % (32 * a.S) != 0 || a.lda % 8 != 0) return -1;
   if (mode == SK_SWIGLU && (a.N & 3)) return -1;
-  if (dtype == MIA_F16) skinny_launch_t<F16>(a, mode, s); else skinny_launch_t<BF16>(a, mode, s);
+  if (dtype == MIA_F16) skinny_launch_t<F16>(a, mode, free_partition, s); else skinny_launch_t<BF16>(a, mode, free_partition, s);
   return 0;
 }
+int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) { return skinny_gemm_launch_p(a, mode, dtype, false, s); }
 
 
 template <typename T, bool M16>
@@ -1033,16 +1136,20 @@ int skinny_gemm_q4_launch(const SkinnyArgs& a, const uint32_t* wfrag, const uint
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s) { return skinny_gemm_launch(a, mode, w->dtype, s); }
+int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s) { return skinny_gemm_launch_p(a, mode, w->dtype, true, s); }
 
 int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const void* vc, void* out, int fixed_keys, int cap_keys,
                          hipStream_t s, float* qk_out, const int32_t* head_slot, int n_slots, int qk_ctx) {
   if (cap_keys > DEC_MAX_KEYS) return -1;
   dim3 grid(w->dims.n_text_head, w->cur_B), block(256);
-  if (w->dtype == MIA_F16)
-    hipLaunchKernelGGL(dec_attention<F16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->clip.pos, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f, qk_out, head_slot, n_slots, qk_ctx);
-  else
-    hipLaunchKernelGGL(dec_attention<BF16>, grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, (uint16_t*)out, w->clip.pos, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f, qk_out, head_slot, n_slots, qk_ctx);
+#define ATT(T_, U_, NTL_)                                                                                                            \
+  hipLaunchKernelGGL((dec_attention<T_, U_, NTL_>), grid, block, 0, s, (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc,   \
+                     (uint16_t*)out, w->clip.pos, fixed_keys, cap_keys, w->dims.n_text_head, 0.125f, qk_out, head_slot, n_slots, qk_ctx)
+  // cross attention (fixed_keys = the 1500 encoder positions): bandwidth-bound streaming of 2 x 192 KB per (clip, head), non-temporal;
+  // self attention: at most n_text_ctx cached keys, latency-bound.  (U = 8 was measured: 10 us per step SLOWER than U = 4.)
+  if (w->dtype == MIA_F16) { if (fixed_keys > 0) ATT(F16, 4, true); else ATT(F16, 4, false); }
+  else { if (fixed_keys > 0) ATT(BF16, 4, true); else ATT(BF16, 4, false); }
+#undef ATT
   return 0;
 }
 

@@ -117,6 +117,7 @@ struct mia_whisper {
   int32_t* out_tokens = nullptr;      // int32 [B][n_ctx] compacted outputs
   float* out_avg = nullptr;           // fp32 [B]
   hipGraphExec_t step_graph = nullptr;
+  hipGraphExec_t step_graph_n = nullptr;   // DEC_GRAPH_STEPS consecutive steps in one graph (one replay gap instead of DEC_GRAPH_STEPS)
   DecodeParams graph_params{};
   bool graph_valid = false;
 };

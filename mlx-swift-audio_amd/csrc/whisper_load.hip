@@ -234,6 +234,7 @@ extern "C" void mia_whisper_free(mia_whisper* w) {
   (void)hipSetDevice(w->ctx->device);
   (void)hipStreamSynchronize(w->ctx->stream);
   if (w->step_graph) (void)hipGraphExecDestroy(w->step_graph);
+  if (w->step_graph_n) (void)hipGraphExecDestroy(w->step_graph_n);
   for (void* p : w->batch_allocs) (void)hipFree(p);
   for (void* p : w->allocs) (void)hipFree(p);
   if (w->parent) w->parent->n_clones -= 1;
