@@ -4,6 +4,20 @@
 
 enum { SK_OUT16 = 0, SK_OUTF32 = 1, SK_PARTIAL = 2, SK_QKV = 3, SK_SWIGLU = 4 };
 
+// ---- MFMA-fragment order (the Whisper decode step's GEMM operands) -------------------------------------------------------------
+// v_mfma_f32_16x16x32 takes, per lane (r = lane & 15, c = lane >> 4), the 8 consecutive K-values 8c..8c+7 of row r.  Stored row-major,
+// one wave instruction gathers 16 rows x 64 B (16 half cache lines whose 2560-byte stride maps them onto a few L2 channels); stored in
+// fragment order it is ONE contiguous 1 KB.  tools/micro/skinny_probe.hip measures the difference on the decoder's fc1 shape
+// (N 5120, K 1280, 32 rows): 11.9 us row-major -> 10.0 us with the weights in fragment order -> 8.3 us with the activations too.
+//   activations [32 z][K]:  element (m, k) -> ((((m >> 5) * (K >> 5) + (k >> 5)) * 2 + ((m >> 4) & 1)) * 64 + ((k >> 3) & 3) * 16 + (m & 15)) * 8 + (k & 7)
+//   weights     [N][K]:     element (n, k) -> (((n >> 4) * (K >> 5) + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7), rows padded to 16
+__host__ __device__ inline int64_t afrag_index(int m, int k, int K) {
+  return ((((int64_t)(m >> 5) * (K >> 5) + (k >> 5)) * 2 + ((m >> 4) & 1)) * 64 + ((k >> 3) & 3) * 16 + (m & 15)) * 8 + (k & 7);
+}
+__host__ __device__ inline int64_t wfrag_index(int n, int k, int K) {
+  return (((int64_t)(n >> 4) * (K >> 5) + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7);
+}
+
 struct SkinnyArgs {
   const uint16_t* A; int64_t lda;        // [M][K]
   const uint16_t* W;                     // [N][K]
@@ -12,11 +26,15 @@ struct SkinnyArgs {
   uint16_t* cache_k; uint16_t* cache_v;  // QKV: [B][H][n_ctx][64] of this layer
   const int32_t* pos;                    // QKV: per-row (clip) cache position
   int M, N, K, S, act, D, H, n_ctx;
+  int out_frag = 0;                      // fragment-order kernels, OUT16: write `out` in activation fragment order (row length N)
 };
 
 int dec_launch_embed_ln(mia_whisper* w, const LNW& ln, hipStream_t s);
 int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln, hipStream_t s);
+// Whisper step: a.A in activation fragment order, a.W in weight fragment order (LinearW::wf)
 int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s);
+// row-major [N][K] 16-bit -> weight fragment order (dst holds ceil(N/16)*16*K elements; rows past N are zero)
+int dec_launch_repack_wfrag(const void* src, void* dst, int N, int K, hipStream_t s);
 // model-independent form (dtype = MIA_BF16 | MIA_F16); SK_SWIGLU: W rows interleaved gate/up, out[m][n/2] = silu(g)*u (16-bit)
 int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s);
 // MLX-affine 4-bit weights in fragment order (decode_kernels.hip: skinny_gemm_q4); modes SK_OUT16 / SK_OUTF32 / SK_PARTIAL / SK_SWIGLU

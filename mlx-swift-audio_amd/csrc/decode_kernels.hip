@@ -27,9 +27,10 @@ __device__ __forceinline__ float block256_sum(float v, float* sh) {
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// h is written in activation FRAGMENT order (decode.h): the row is the A operand of the step's next skinny GEMM
 template <typename T>
 __device__ __forceinline__ void row_layernorm_store(const f32x4 (&v)[ROW_NV], int nv, int D, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, uint16_t* __restrict__ hrow, float* sh) {
+                                                    const float* __restrict__ beta, uint16_t* __restrict__ h, int row, float* sh) {
   const int tid = threadIdx.x;
   // gamma / beta do not depend on the statistics: fetch them first, so their L2 round trip overlaps the two block reductions
   f32x4 gm[ROW_NV], bt[ROW_NV];
@@ -58,7 +59,7 @@ __device__ __forceinline__ void row_layernorm_store(const f32x4 (&v)[ROW_NV], in
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * gm[i][j] + bt[i][j];
-    *reinterpret_cast<u32x2*>(hrow + 4 * c) = (u32x2){pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+    *reinterpret_cast<u32x2*>(h + afrag_index(row, 4 * c, D)) = (u32x2){pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
   }
 }
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void dec_embed_ln(const int32_t* __restrict__ 
       *reinterpret_cast<f32x4*>(xr + 4 * c) = v[i];
     } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  row_layernorm_store<T>(v, nv, D, gamma, beta, h + (int64_t)b * D, sh);
+  row_layernorm_store<T>(v, nv, D, gamma, beta, h, b, sh);
 }
 
 // x[b] += bias + sum_s partial[s][b];  h[b] = LN(x[b])        (residual add + next LayerNorm, fixed-order split-K sum)
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void dec_reduce_ln(const float* __restrict__ p
       *reinterpret_cast<f32x4*>(xr + 4 * c) = a;
     } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  row_layernorm_store<T>(v, nv, D, gamma, beta, h + (int64_t)b * D, sh);
+  row_layernorm_store<T>(v, nv, D, gamma, beta, h, b, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -338,6 +339,200 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
     }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
   skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The Whisper step's skinny GEMMs: both operands in MFMA-fragment order (decode.h), so every wave load instruction is one
+// contiguous 1 KB, and an epilogue that stores a lane's 4 consecutive columns as one 8- or 16-byte word.
+// Measured on the fc1 shape (tools/micro/skinny_probe.hip, N 5120, K 1280, 32 rows, HBM-cold weights): row-major operands + scalar
+// stores 11.9 us; weights in fragment order 10.0; activations too 8.3; without the scalar epilogue 5.8; 13 MB streamed by a kernel
+// that does nothing else 4.1.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void repack_wfrag(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int N, int K) {
+  // one thread per 16-byte fragment chunk: (tile, kstep, lane) <- row 16 tile + (lane & 15), columns 32 kstep + 8 (lane >> 4) .. +7
+  const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int ksteps = K >> 5;
+  const int64_t total = (int64_t)((N + 15) >> 4) * ksteps * 64;
+  if (chunk >= total) return;
+  const int lane = (int)(chunk & 63);
+  const int64_t tk = chunk >> 6;
+  const int kstep = (int)(tk % ksteps), tile = (int)(tk / ksteps);
+  const int n = tile * 16 + (lane & 15), k = kstep * 32 + 8 * (lane >> 4);
+  s16x8 v = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  if (n < N) v = *reinterpret_cast<const s16x8*>(src + (int64_t)n * K + k);
+  *reinterpret_cast<s16x8*>(dst + chunk * 8) = v;
+}
+
+int dec_launch_repack_wfrag(const void* src, void* dst, int N, int K, hipStream_t s) {
+  if (N <= 0 || K <= 0 || K % 32 != 0) return -1;
+  const int64_t total = (int64_t)((N + 15) / 16) * (K / 32) * 64;
+  hipLaunchKernelGGL(repack_wfrag<BF16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, N, K);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// lane holds C[m = m0 + mt*16 + r][n = n0 + 16t + 4c + j], j = 0..3: one vector store per (t, mt)
+template <typename T, int MODE, int NT>
+__device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane) {
+  static_assert(MODE != SK_SWIGLU, "the fragment-order kernels serve the Whisper step");
+  const int r = lane & 15, c = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + 4 * c;
+    if (n >= a.N) continue;
+    const bool full = n + 3 < a.N;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE != SK_PARTIAL && a.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (n + j < a.N) bs[j] = a.bias[n + j];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = m0 + mt * 16 + r;
+      if (m >= a.M) continue;
+      f32x4 v = acc[t][mt];
+      if (MODE == SK_PARTIAL) {
+        float* dst = reinterpret_cast<float*>(a.out) + ((int64_t)split * a.M + m) * a.N + n;
+        if (full && (a.N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+        else { for (int j = 0; j < 4; ++j) if (n + j < a.N) dst[j] = v[j]; }
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] += bs[j]; if (a.act == MIA_ACT_GELU) v[j] = gelu_erf(v[j]); }
+      if (MODE == SK_OUTF32) {
+        float* dst = reinterpret_cast<float*>(a.out) + (int64_t)m * a.ldo + n;
+        if (full && (a.ldo & 1) == 0) {
+          *reinterpret_cast<f32x2*>(dst) = (f32x2){v[0], v[1]};
+          *reinterpret_cast<f32x2*>(dst + 2) = (f32x2){v[2], v[3]};
+        } else { for (int j = 0; j < 4; ++j) if (n + j < a.N) dst[j] = v[j]; }
+        continue;
+      }
+      const u32x2 pk = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+      uint16_t* o16 = reinterpret_cast<uint16_t*>(a.out);
+      if (MODE == SK_OUT16) {
+        if (a.out_frag) { *reinterpret_cast<u32x2*>(o16 + afrag_index(m, n, a.N)) = pk; continue; }   // host-checked: N % 16 == 0
+        uint16_t* dst = o16 + (int64_t)m * a.ldo + n;
+        if (full && (a.ldo & 3) == 0) *reinterpret_cast<u32x2*>(dst) = pk;
+        else { for (int j = 0; j < 4; ++j) if (n + j < a.N) dst[j] = T::from_f32(v[j]); }
+        continue;
+      }
+      // SK_QKV (host-checked: D % 64 == 0, N == 3 D): [0,D) -> q row-major, [D,2D) -> self K cache, [2D,3D) -> self V cache at pos[m]
+      if (n < a.D) { *reinterpret_cast<u32x2*>(o16 + (int64_t)m * a.ldo + n) = pk; continue; }
+      const int hd = (n - a.D) % a.D, h = hd >> 6, d = hd & 63;
+      uint16_t* cache = n < 2 * a.D ? a.cache_k : a.cache_v;
+      *reinterpret_cast<u32x2*>(cache + (((int64_t)m * a.H + h) * a.n_ctx + a.pos[m]) * 64 + d) = pk;
+    }
+  }
+}
+
+// short K slice per wave (NSTEP K-steps, host-checked K == 32 * S * NW * NSTEP): every load ahead of the first MFMA
+template <typename T, int MODE, int NT, int NSTEP, int NW>
+__global__ __launch_bounds__(64 * NW) void dec_skinny_fflat(SkinnyArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int split = blockIdx.y, z = blockIdx.z;
+  const int ksteps = a.K >> 5, tiles = (a.N + 15) >> 4;
+  const int ks0 = (split * NW + wave) * NSTEP;
+  const uint16_t* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int tile = blockIdx.x * NT + t; tile = tile < tiles ? tile : tiles - 1;
+    wp[t] = a.W + (((int64_t)tile * ksteps + ks0) * 64 + lane) * 8;
+  }
+  const uint16_t* ap = a.A + ((((int64_t)z * ksteps + ks0) * 2) * 64 + lane) * 8;
+  s16x8 fw[NSTEP][NT], fa0[NSTEP], fa1[NSTEP];
+#pragma unroll
+  for (int u = 0; u < NSTEP; ++u) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) fw[u][n] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp[n] + 512 * u));
+    fa0[u] = *reinterpret_cast<const s16x8*>(ap + 1024 * u);
+    fa1[u] = *reinterpret_cast<const s16x8*>(ap + 1024 * u + 512);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep every load ahead of the first MFMA
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int u = 0; u < NSTEP; ++u)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      acc[n][0] = T::mfma16(fw[u][n], fa0[u], acc[n][0]);
+      acc[n][1] = T::mfma16(fw[u][n], fa1[u], acc[n][1]);
+    }
+  if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
+  skinny_epilogue_v<T, MODE, NT>(a, acc, blockIdx.x * (16 * NT), z * 32, split, lane);
+}
+
+// any K slice per wave (K == 32 * S * NW * steps): a ring of four register batches of KB K-steps, three in flight
+template <typename T, int MODE, int NT, int KB, int NW>
+__global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int split = blockIdx.y, z = blockIdx.z;
+  const int ksteps = a.K >> 5, tiles = (a.N + 15) >> 4;
+  const int per_wave = ksteps / (a.S * NW);
+  const int ks0 = (split * NW + wave) * per_wave;
+  const uint16_t* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int tile = blockIdx.x * NT + t; tile = tile < tiles ? tile : tiles - 1;
+    wp[t] = a.W + (((int64_t)tile * ksteps + ks0) * 64 + lane) * 8;
+  }
+  const uint16_t* ap = a.A + ((((int64_t)z * ksteps + ks0) * 2) * 64 + lane) * 8;
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  struct Batch { s16x8 w[KB][NT], a0[KB], a1[KB]; };
+  auto load_batch = [&](Batch& t, int ks) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) t.w[u][n] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp[n] + 512 * (ks + u)));
+      t.a0[u] = *reinterpret_cast<const s16x8*>(ap + 1024 * (ks + u));
+      t.a1[u] = *reinterpret_cast<const s16x8*>(ap + 1024 * (ks + u) + 512);
+    }
+  };
+  auto mma_batch = [&](const Batch& t) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[n][0] = T::mfma16(t.w[u][n], t.a0[u], acc[n][0]);
+        acc[n][1] = T::mfma16(t.w[u][n], t.a1[u], acc[n][1]);
+      }
+  };
+  const int nb = per_wave / KB;
+  int ks = 0;
+  if (nb > 0) {
+    Batch b0, b1, b2, b3;
+    load_batch(b0, 0);
+    if (nb > 1) load_batch(b1, KB);
+    if (nb > 2) load_batch(b2, 2 * KB);
+    for (int i = 0; i < nb; i += 4) {
+      if (i + 3 < nb) load_batch(b3, (i + 3) * KB);
+      mma_batch(b0);
+      if (i + 1 >= nb) break;
+      if (i + 4 < nb) load_batch(b0, (i + 4) * KB);
+      mma_batch(b1);
+      if (i + 2 >= nb) break;
+      if (i + 5 < nb) load_batch(b1, (i + 5) * KB);
+      mma_batch(b2);
+      if (i + 3 >= nb) break;
+      if (i + 6 < nb) load_batch(b2, (i + 6) * KB);
+      mma_batch(b3);
+    }
+    ks = nb * KB;
+  }
+  for (; ks < per_wave; ++ks) {
+    const s16x8 fa0 = *reinterpret_cast<const s16x8*>(ap + 1024 * ks);
+    const s16x8 fa1 = *reinterpret_cast<const s16x8*>(ap + 1024 * ks + 512);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const s16x8 fw = *reinterpret_cast<const s16x8*>(wp[n] + 512 * ks);
+      acc[n][0] = T::mfma16(fw, fa0, acc[n][0]);
+      acc[n][1] = T::mfma16(fw, fa1, acc[n][1]);
+    }
+  }
+  if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
+  skinny_epilogue_v<T, MODE, NT>(a, acc, blockIdx.x * (16 * NT), z * 32, split, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -560,7 +755,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   __syncthreads();
   if (tid < 64) {
     const float o = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) / sum;
-    out[(int64_t)b * D + h * 64 + tid] = T::from_f32(o);
+    out[afrag_index(b, h * 64 + tid, D)] = T::from_f32(o);   // fragment order: the A operand of the output projection
   }
 }
 
@@ -991,7 +1186,7 @@ __global__ __launch_bounds__(256) void dec_head_final(HeadBufs hb, DecodeParams 
       *reinterpret_cast<f32x4*>(xr + 4 * c) = v[i];
     } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  row_layernorm_store<T>(v, nv, D, ne.gamma, ne.beta, ne.h + (int64_t)b * D, sh);
+  row_layernorm_store<T>(v, nv, D, ne.gamma, ne.beta, ne.h, b, sh);
 }
 
 // compact outputs: generated tokens with EOT (and anything after) stripped; avg_logprob
@@ -1034,36 +1229,33 @@ int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln
 }
 
 // short-K-slice form (dec_skinny_flat): K per split = NW x 32 x NSTEP for one of the instantiated NSTEP
-// `free_partition`: the caller accepts any split of K over waves (the Whisper step).  The LM step does not: its packed-weight twin
-// (skinny_gemm_q4) must sum in the same order, so there the flat form is taken only where it keeps the ring kernel's 4-wave split.
-template <typename T, int MODE, int NT>
-static bool skinny_flat_try(const SkinnyArgs& a, bool free_partition, hipStream_t s) {
-  if (std::getenv("MIA_SKINNY_NO_FLAT")) return false;   // A/B switch for tools/ (the ring kernel gives bit-identical results)
-  const int tiles = (a.N + 16 * NT - 1) / (16 * NT), zb = (a.M + 31) / 32;
+// short-K-slice form (dec_skinny_flat) of the row-major kernel, taken only where it keeps the ring kernel's 4-wave split of K:
+// the LM step's packed-weight twin (skinny_gemm_q4) must sum in the same order as its 16-bit form
+template <typename T, int MODE>
+static bool skinny_flat_try(const SkinnyArgs& a, hipStream_t s) {
+  const int tiles = (a.N + 15) / 16, zb = (a.M + 31) / 32;
   const int64_t wgs = (int64_t)tiles * a.S * zb;
-  if (a.K % (32 * a.S) != 0 || wgs > 4096) return false;
+  if (a.K % (128 * a.S) != 0 || wgs > 1024 || a.K / a.S < 512) return false;
   const int per_split = a.K / a.S;
-  if (!free_partition && !(MODE != SK_OUTF32 && wgs <= 1024 && a.K % (128 * a.S) == 0 && per_split >= 512)) return false;
   const dim3 grid(tiles, a.S, zb);
-#define FLAT(NW_, NSTEP_)                                                                                             \
-  if (per_split == NW_ * 32 * NSTEP_) {                                                                               \
-    hipLaunchKernelGGL((dec_skinny_flat<T, MODE, NT, NSTEP_, NW_>), grid, dim3(64 * NW_), 0, s, a);                    \
+#define FLAT(NSTEP_)                                                                                                  \
+  if (per_split == 4 * 32 * NSTEP_) {                                                                                 \
+    hipLaunchKernelGGL((dec_skinny_flat<T, MODE, 1, NSTEP_, 4>), grid, dim3(256), 0, s, a);                            \
     return true;                                                                                                      \
   }
-  if (wgs <= 128 && free_partition) { FLAT(8, 5) }   // a grid that leaves half the CUs empty: twice the waves, half the slice
-  FLAT(4, 10) FLAT(4, 5) FLAT(4, 8) FLAT(4, 6) FLAT(4, 4) FLAT(4, 3)
+  FLAT(10) FLAT(5) FLAT(8) FLAT(6) FLAT(4)
 #undef FLAT
   return false;
 }
 
 template <typename T>
-static void skinny_launch_t(const SkinnyArgs& a, int mode, bool fp, hipStream_t s) {
+static void skinny_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
   switch (mode) {
-    case SK_OUTF32: break;   // the vocabulary-wide GEMM is bandwidth-bound: the ring kernel below (measured: flat forms are 11-14 us slower)
-    case SK_OUT16: if (skinny_flat_try<T, SK_OUT16, 1>(a, fp, s)) return; break;
-    case SK_PARTIAL: if (skinny_flat_try<T, SK_PARTIAL, 1>(a, fp, s)) return; break;
-    case SK_SWIGLU: if (skinny_flat_try<T, SK_SWIGLU, 1>(a, fp, s)) return; break;
-    default: if (skinny_flat_try<T, SK_QKV, 1>(a, fp, s)) return; break;
+    case SK_OUTF32: break;   // bandwidth-bound: the ring kernel (measured: flat forms are 11-14 us slower on the 51866-wide head)
+    case SK_OUT16: if (skinny_flat_try<T, SK_OUT16>(a, s)) return; break;
+    case SK_PARTIAL: if (skinny_flat_try<T, SK_PARTIAL>(a, s)) return; break;
+    case SK_SWIGLU: if (skinny_flat_try<T, SK_SWIGLU>(a, s)) return; break;
+    default: if (skinny_flat_try<T, SK_QKV>(a, s)) return; break;
   }
   if (mode == SK_OUTF32) {   // the vocabulary-wide logits GEMM: 64 columns per wave
     dim3 grid((a.N + 63) / 64, a.S, (a.M + 31) / 32);
@@ -1087,13 +1279,12 @@ static void skinny_launch_t(const SkinnyArgs& a, int mode, bool fp, hipStream_t 
 #undef SK_LAUNCH
 }
 
-static int skinny_gemm_launch_p(const SkinnyArgs& a, int mode, int dtype, bool free_partition, hipStream_t s) {
+int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) {
   if (a.K % (32 * a.S) != 0 || a.lda % 8 != 0) return -1;
   if (mode == SK_SWIGLU && (a.N & 3)) return -1;
-  if (dtype == MIA_F16) skinny_launch_t<F16>(a, mode, free_partition, s); else skinny_launch_t<BF16>(a, mode, free_partition, s);
+  if (dtype == MIA_F16) skinny_launch_t<F16>(a, mode, s); else skinny_launch_t<BF16>(a, mode, s);
   return 0;
 }
-int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) { return skinny_gemm_launch_p(a, mode, dtype, false, s); }
 
 
 template <typename T, bool M16>
@@ -1136,7 +1327,46 @@ int skinny_gemm_q4_launch(const SkinnyArgs& a, const uint32_t* wfrag, const uint
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s) { return skinny_gemm_launch_p(a, mode, w->dtype, true, s); }
+// ---- the Whisper step: fragment-order operands (a.A: activation fragments, a.W: LinearW::wf)
+template <typename T, int MODE>
+static int skinny_frag_launch_m(const SkinnyArgs& a, hipStream_t s) {
+  const int tiles = (a.N + 15) / 16, zb = (a.M + 31) / 32, ksteps = a.K / 32;
+  if (MODE == SK_OUTF32) {   // the vocabulary-wide logits GEMM (bandwidth-bound): 64 columns per one-wave workgroup, ring pipeline
+    hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 4, 2, 1>), dim3((tiles + 3) / 4, a.S, zb), dim3(64), 0, s, a);
+    return 0;
+  }
+  // K of a split is divided over the most waves of {4, 2, 1} that take whole K-steps (summed through LDS in wave order)
+  const int per_split = ksteps / a.S;
+  const int NW = per_split % 4 == 0 ? 4 : per_split % 2 == 0 ? 2 : 1;
+  const int nstep = per_split / NW;
+  const dim3 grid(tiles, a.S, zb);
+#define FF(NS_)                                                                                                       \
+  if (NW == 4 && nstep == NS_) { hipLaunchKernelGGL((dec_skinny_fflat<T, MODE, 1, NS_, 4>), grid, dim3(256), 0, s, a); return 0; }
+  FF(10) FF(5) FF(8) FF(6) FF(4) FF(3) FF(2) FF(1)
+#undef FF
+  if (NW == 4) hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 4>), grid, dim3(256), 0, s, a);
+  else if (NW == 2) hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 2>), grid, dim3(128), 0, s, a);
+  else hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 1>), grid, dim3(64), 0, s, a);
+  return 0;
+}
+
+template <typename T>
+static int skinny_frag_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
+  switch (mode) {
+    case SK_OUT16: return skinny_frag_launch_m<T, SK_OUT16>(a, s);
+    case SK_OUTF32: return skinny_frag_launch_m<T, SK_OUTF32>(a, s);
+    case SK_PARTIAL: return skinny_frag_launch_m<T, SK_PARTIAL>(a, s);
+    case SK_QKV: return skinny_frag_launch_m<T, SK_QKV>(a, s);
+    default: return -1;
+  }
+}
+
+int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s) {
+  if (!a.A || !a.W || !a.out || a.M <= 0 || a.N <= 0 || a.S <= 0 || a.K % (32 * a.S) != 0) return -1;
+  if (mode == SK_QKV && (a.D % 64 != 0 || a.N != 3 * a.D || (a.ldo & 3) || !a.cache_k || !a.cache_v || !a.pos)) return -1;
+  if (mode == SK_OUT16 && a.out_frag && a.N % 32 != 0) return -1;
+  return w->dtype == MIA_F16 ? skinny_frag_launch_t<F16>(a, mode, s) : skinny_frag_launch_t<BF16>(a, mode, s);
+}
 
 int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const void* vc, void* out, int fixed_keys, int cap_keys,
                          hipStream_t s, float* qk_out, const int32_t* head_slot, int n_slots, int qk_ctx) {

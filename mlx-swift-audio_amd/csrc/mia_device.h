@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;   // 8 x f16 (f16 MF
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // ---- 16-bit storage types: bf16 (tag 2) and f16 (tag 1) share every kernel via this trait --------
 struct BF16 {

@@ -20,6 +20,7 @@
 
 struct LinearW {
   void* w = nullptr;       // 16-bit [N][K]
+  void* wf = nullptr;      // decoder only: the same matrix in MFMA-fragment order (decode.h), read by the step's skinny GEMMs
   float* b = nullptr;      // fp32 [N] or null
   int N = 0, K = 0;
 };
@@ -73,7 +74,8 @@ struct mia_whisper {
   float* enc_pos = nullptr;           // [n_audio_ctx][D]
   std::vector<EncBlockW> enc;
   LNW ln_post;
-  void* tok_emb = nullptr;            // 16-bit [V][D]
+  void* tok_emb = nullptr;            // 16-bit [V][D]  (row gather for the embedding)
+  void* tok_emb_f = nullptr;          // the same in MFMA-fragment order (the logits GEMM of the decode step)
   float* dec_pos = nullptr;           // [n_text_ctx][D]
   std::vector<DecBlockW> dec;
   LNW dec_ln;

@@ -61,9 +61,11 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p, const AlignHook* hook = 
   hipStream_t s = w->ctx->stream;
   const int B = w->cur_B, D = p.D, H = p.H, C = p.n_ctx, T = w->dims.n_audio_ctx;
   const uint16_t* dh = (const uint16_t*)w->dh;
+  // A operands (dh, da, dg) and weights (LinearW::wf) are in MFMA-fragment order (decode.h); out_frag: the output is the next GEMM's A
   auto skinny = [&](const uint16_t* A, int64_t lda, const LinearW& lw, bool use_bias, void* out, int64_t ldo, int S, int act, int mode,
-                    uint16_t* ck = nullptr, uint16_t* cv = nullptr) {
-    SkinnyArgs a{A, lda, (const uint16_t*)lw.w, use_bias ? lw.b : nullptr, out, ldo, ck, cv, w->clip.pos, B, lw.N, lw.K, S, act, D, H, C};
+                    uint16_t* ck = nullptr, uint16_t* cv = nullptr, int out_frag = 0) {
+    SkinnyArgs a{A, lda, (const uint16_t*)lw.wf, use_bias ? lw.b : nullptr, out, ldo, ck, cv, w->clip.pos, B, lw.N, lw.K, S, act, D, H, C};
+    a.out_frag = out_frag;
     return dec_launch_skinny(w, a, mode, s);
   };
   const int S_d = pick_split(D, 2), S_4d = pick_split(4 * D, 4);   // x 4 waves of intra-workgroup split-K each
@@ -87,12 +89,12 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p, const AlignHook* hook = 
     if (skinny((const uint16_t*)w->da, D, b.cout, false, w->partial, 0, S_d, MIA_ACT_NONE, SK_PARTIAL)) return -1;
     dec_launch_reduce_ln(w, S_d, b.cout.b, b.mlp_ln, s);
     // MLP
-    if (skinny(dh, D, b.mlp1, true, w->dg, 4 * D, 1, MIA_ACT_GELU, SK_OUT16)) return -1;
+    if (skinny(dh, D, b.mlp1, true, w->dg, 4 * D, 1, MIA_ACT_GELU, SK_OUT16, nullptr, nullptr, 1)) return -1;
     if (skinny((const uint16_t*)w->dg, 4 * D, b.mlp2, false, w->partial, 0, S_4d, MIA_ACT_NONE, SK_PARTIAL)) return -1;
     dec_launch_reduce_ln(w, S_4d, b.mlp2.b, l + 1 < p.L ? w->dec[l + 1].attn_ln : w->dec_ln, s);
   }
   {  // logits = ln(x) . E^T (tied embedding, TextDecoder.swift:93)
-    LinearW e; e.w = w->tok_emb; e.N = p.V; e.K = D;
+    LinearW e; e.w = w->tok_emb; e.wf = w->tok_emb_f; e.N = p.V; e.K = D;
     if (skinny(dh, D, e, false, w->logits, p.V, 1, MIA_ACT_NONE, SK_OUTF32)) return -1;
   }
   if (hook) {

@@ -69,10 +69,12 @@ int whisper_reserve(mia_whisper* w, int B) {
   A(self_k, L * B * C * D * 2, true);
   A(self_v, L * B * C * D * 2, true);
   A(dx, (size_t)B * D * 4, false);
-  A(dh, (size_t)B * D * 2, false);
+  // GEMM operands of the decode step live in MFMA-fragment order (decode.h): whole 32-row blocks, rows past B stay zero
+  const size_t B32 = align_up((size_t)B, 32);
+  A(dh, B32 * D * 2, true);
   A(dq, (size_t)B * D * 2, false);
-  A(da, (size_t)B * D * 2, false);
-  A(dg, (size_t)B * 4 * D * 2, false);
+  A(da, B32 * D * 2, true);
+  A(dg, B32 * 4 * D * 2, true);
   A(partial, (size_t)16 * B * D * 4, false);
   A(logits, (size_t)B * V * 4, false);
   A(tokens, (size_t)B * C * 4, true);

@@ -3,7 +3,7 @@
 // reference's Module property paths (Layers/*.swift @ModuleInfo keys).
 #include <cmath>
 
-#include "whisper.h"
+#include "decode.h"
 
 namespace {
 
@@ -224,6 +224,22 @@ extern "C" mia_whisper* mia_whisper_load(mia_ctx* ctx, const mia_whisper_dims* d
   }
   w->dec_ln = L.ln("decoder.ln", D);
   if (!L.err.empty()) { mia_whisper_free(w); return fail(L.err); }
+  {  // the decode step reads its weights in MFMA-fragment order (decode.h): one repack per matrix, on the device
+    bool ok = true;
+    auto frag = [&](const void* src, int N, int K) -> void* {
+      if (!ok || !src) return nullptr;
+      void* dst = nullptr;
+      const size_t bytes = (size_t)((N + 15) / 16) * 16 * K * 2;
+      if (K % 32 != 0 || hipMalloc(&dst, bytes) != hipSuccess) { ok = false; return nullptr; }
+      w->allocs.push_back(dst);
+      if (dec_launch_repack_wfrag(src, dst, N, K, ctx->stream) != 0) ok = false;
+      return dst;
+    };
+    for (DecBlockW& b : w->dec)
+      for (LinearW* lw : {&b.qkv, &b.out, &b.cq, &b.cout, &b.mlp1, &b.mlp2}) lw->wf = frag(lw->w, lw->N, lw->K);
+    w->tok_emb_f = frag(w->tok_emb, d.n_vocab, D);
+    if (!ok) { mia_whisper_free(w); return fail("fragment-order repack of the decoder weights failed"); }
+  }
   if (hipDeviceSynchronize() != hipSuccess) { mia_whisper_free(w); return fail("device error during upload"); }
   return w;
 }
@@ -251,7 +267,7 @@ extern "C" mia_whisper* mia_whisper_clone(mia_whisper* src, mia_ctx* ctx) {
   mia_whisper* w = new mia_whisper();
   w->ctx = ctx; w->dims = root->dims; w->dtype = root->dtype; w->kpad_conv1 = root->kpad_conv1;
   w->conv1 = root->conv1; w->conv2 = root->conv2; w->enc_pos = root->enc_pos; w->enc = root->enc; w->ln_post = root->ln_post;
-  w->tok_emb = root->tok_emb; w->dec_pos = root->dec_pos; w->dec = root->dec; w->dec_ln = root->dec_ln;
+  w->tok_emb = root->tok_emb; w->tok_emb_f = root->tok_emb_f; w->dec_pos = root->dec_pos; w->dec = root->dec; w->dec_ln = root->dec_ln;
   w->parent = root;
   root->n_clones += 1;
   return w;
