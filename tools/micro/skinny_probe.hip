@@ -175,12 +175,21 @@ int main() {
   RUN("mlp2 flat  NT1 NS10 NW4 S4 grid 80x4", 1280, 5120, 4, MIA_ACT_NONE, (dec_skinny_flat<BF16, SK_PARTIAL, 1, 10, 4>), 80, 256);
   RUN("mlp2 flat  NT1 NS5 NW8 S4 grid 80x4", 1280, 5120, 4, MIA_ACT_NONE, (dec_skinny_flat<BF16, SK_PARTIAL, 1, 5, 8>), 80, 512);
   RUN("mlp2 flat  NT1 NS5 NW4 S8 grid 80x8", 1280, 5120, 8, MIA_ACT_NONE, (dec_skinny_flat<BF16, SK_PARTIAL, 1, 5, 4>), 80, 256);
-  // ---- logits shape: N 51866, K 1280, fp32 out (132.8 MB)
-  RUN("logits ring NT4 KB2 NW1 grid 811 x 64 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_gemm<BF16, SK_OUTF32, 4, 2, 1>), 811, 64);
-  RUN("logits ring NT2 KB2 NW1 grid 1621 x 64 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_gemm<BF16, SK_OUTF32, 2, 2, 1>), 1621, 64);
-  RUN("logits ring NT4 KB2 NW4 grid 811 x 256 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_gemm<BF16, SK_OUTF32, 4, 2, 4>), 811, 256);
-  RUN("logits ring NT2 KB2 NW4 grid 1621 x 256 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_gemm<BF16, SK_OUTF32, 2, 2, 4>), 1621, 256);
-  RUN("logits ring NT4 KB2 NW2 grid 811 x 128 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_gemm<BF16, SK_OUTF32, 4, 2, 2>), 811, 128);
-  RUN("logits ring NT8 KB1 NW4 grid 406 x 256 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_gemm<BF16, SK_OUTF32, 8, 1, 4>), 406, 256);
+  // ---- logits shape: N 51866, K 1280, fp32 out (132.8 MB), fragment-order operands (the pool's bytes stand in for both layouts)
+  RUN("logits fring NT4 KB2 NW1 grid 811 x 64 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_fring<BF16, SK_OUTF32, 4, 2, 1>), 811, 64);
+  RUN("logits fring NT4 KB4 NW1 grid 811 x 64 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_fring<BF16, SK_OUTF32, 4, 4, 1>), 811, 64);
+  RUN("logits fring NT2 KB4 NW1 grid 1621 x 64 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_fring<BF16, SK_OUTF32, 2, 4, 1>), 1621, 64);
+  RUN("logits fring NT2 KB2 NW2 grid 1621 x 128 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_fring<BF16, SK_OUTF32, 2, 2, 2>), 1621, 128);
+  RUN("logits fring NT4 KB2 NW2 grid 811 x 128 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_fring<BF16, SK_OUTF32, 4, 2, 2>), 811, 128);
+  RUN("logits fring NT1 KB4 NW1 grid 3242 x 64 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_fring<BF16, SK_OUTF32, 1, 4, 1>), 3242, 64);
+  RUN("logits fflat NT1 NS10 NW4 grid 3242 x 256 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_fflat<BF16, SK_OUTF32, 1, 10, 4>), 3242, 256);
+  RUN("logits fflat NT2 NS10 NW4 grid 1621 x 256 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_fflat<BF16, SK_OUTF32, 2, 10, 4>), 1621, 256);
+  RUN("logits fring NT8 KB1 NW1 grid 406 x 64 thr", 51866, 1280, 1, MIA_ACT_NONE, (dec_skinny_fring<BF16, SK_OUTF32, 8, 1, 1>), 406, 64);
+  // library kernels on the step's other shapes
+  RUN("mlp1 fflat NT1 NS10 NW4 grid 320 (library)", 5120, 1280, 1, MIA_ACT_GELU, (dec_skinny_fflat<BF16, SK_OUT16, 1, 10, 4>), 320, 256);
+  RUN("mlp1 fflat NT2 NS10 NW4 grid 160 (library)", 5120, 1280, 1, MIA_ACT_GELU, (dec_skinny_fflat<BF16, SK_OUT16, 2, 10, 4>), 160, 256);
+  RUN("mlp2 fflat NT1 NS10 NW4 S4 grid 80x4 (library)", 1280, 5120, 4, MIA_ACT_NONE, (dec_skinny_fflat<BF16, SK_PARTIAL, 1, 10, 4>), 80, 256);
+  RUN("mlp2 fflat NT1 NS5 NW4 S8 grid 80x8 (library)", 1280, 5120, 8, MIA_ACT_NONE, (dec_skinny_fflat<BF16, SK_PARTIAL, 1, 5, 4>), 80, 256);
+  RUN("oproj fflat NT1 NS5 NW4 S2 grid 80x2 (library)", 1280, 1280, 2, MIA_ACT_NONE, (dec_skinny_fflat<BF16, SK_PARTIAL, 1, 5, 4>), 80, 256);
   return 0;
 }
