@@ -459,6 +459,15 @@ int mia_flow_encode(mia_flow* f, const int32_t* token, int n_token, float* mu, i
  *   mel out float32 [80][T - prompt_feat_len] (channel-major, what CosyHiFTGenerator consumes).  Every buffer lives in `mem`. */
 int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
                        int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, float* mel, int mem);
+/* n_utt utterances through ONE pass of the flow (an MI355X-side addition like mia_lm_generate_ras_batch: the reference synthesises its
+ * sentences one after another, CosyVoice2Model.swift:155-208,467-553).  Every argument of mia_flow_inference becomes an array indexed by
+ * utterance (prompt_token / prompt_feat may be null when every utterance has none; entry u may be null when n_prompt[u] /
+ * prompt_feat_len[u] is 0); mel[u] receives float32 [80][T_u - prompt_feat_len[u]], T_u = upsample_stride (n_token[u] + n_prompt[u]).
+ * The utterances run as stacked sequences padded to the longest one; padding never reaches a valid frame (per-sequence key masks and
+ * zero look-ahead), so mel[u] is bit-identical to the utterance's own mia_flow_inference call.  1 <= n_utt <= 64. */
+int mia_flow_inference_batch(mia_flow* f, int n_utt, const int32_t* const* token, const int32_t* n_token, const int32_t* const* prompt_token,
+                             const int32_t* n_prompt, const float* const* prompt_feat, const int32_t* prompt_feat_len, const float* const* embedding,
+                             const float* const* z, int n_timesteps, float* const* mel, int mem);
 /* The same call with the two switches the modules carry for chunked synthesis:
  *   finalize = 0 drops the encoder's last pre_lookahead_len * upsample_stride frames before the CFM (CosyVoice2Model.swift:504-510), so
  *     T = upsample_stride (n_token + n_prompt) - that trim; z is [80][T] for THAT T and *mel_frames = T - prompt_feat_len;

@@ -107,10 +107,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   // streaming mask: this lane's query sees keys below klim; the workgroup's key walk stops at its last query's limit
+  // (padded batch: keys at or beyond the sequence's own length Tb are masked like a chunk limit; the rows exist -- finite padding --
+  // so their probability is an exact 0 and the walk's length, tiles and order are those of the sequence's own B = 1 call)
+  const int Tb = a.seq_len ? min(a.T, max(1, a.seq_len[b])) : a.T;
   const int qmine = q0 + lq < a.T ? q0 + lq : a.T - 1;
-  const int klim = a.chunk > 0 ? min(a.T, (qmine / a.chunk + 1) * a.chunk) : a.T;
+  const int klim = a.chunk > 0 ? min(Tb, (qmine / a.chunk + 1) * a.chunk) : Tb;
   const int qlast = q0 + 31 < a.T ? q0 + 31 : a.T - 1;
-  const int Tk = a.chunk > 0 ? min(a.T, (qlast / a.chunk + 1) * a.chunk) : a.T;     // workgroup-uniform
+  const int Tk = a.chunk > 0 ? min(Tb, (qlast / a.chunk + 1) * a.chunk) : Tb;       // workgroup-uniform
   const int npairs = (Tk + 32 * NKV - 1) / (32 * NKV);
   load_regs(0);
   for (int kp = 0; kp < npairs; ++kp) {

@@ -25,6 +25,8 @@ struct ConvGemmArgs {
   int x_row_mul = 1;                   // convolution stride: A(m, tap, c) = X[m*x_row_mul + tap*dil - pad][c]
   int gelu = 0;                        // activation on acc + bias (before the residual): 1 = exact-erf GELU, 2 = ELU, 3 = abs, 4 = SiLU, 5 = leaky-ReLU(0.01), 6 = ReLU
   int64_t ldw = 0;                     // row stride of W (0 = taps*Cin, i.e. dense)
+  const int32_t* phase_len = nullptr;  // device [phases], optional (with x_phase_step): sequence z holds phase_len[z] <= T_in valid rows, rows at or
+                                       // beyond it read as zero like rows past T_in (padded stacked sequences under a forward-looking window)
   int x_phase_step = 0;                // rows of X skipped per grid.z phase: stacked sequences of T_in rows each (taps never cross
                                        // a sequence; pair with w_phase_stride = 0, y_row_mul = 1, y_phase_step = rows per sequence)
 };

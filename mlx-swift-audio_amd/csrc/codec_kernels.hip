@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   const int z = blockIdx.z;
   const float* __restrict__ W = g.W + (int64_t)z * g.w_phase_stride;
   const float* __restrict__ X = g.X + (int64_t)z * g.x_phase_step * g.ldx;   // stacked sequences: phase z reads its own rows only
+  const int T_valid = g.phase_len ? min(g.T_in, g.phase_len[z]) : g.T_in;      // padded sequence: rows past its own length are zeros
   const int Ktot = g.taps * g.Cin;
   const int64_t ldw = g.ldw > 0 ? g.ldw : Ktot;
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
       for (int i = 0; i < 2 * WM; ++i) {
         const int m = m0 + s_row + 32 * i;
         const int xr = m * g.x_row_mul + tap * g.dil - g.pad;    // host checks that M * x_row_mul fits 31 bits
-        const bool ok = kin && m < g.M && xr >= 0 && xr < g.T_in;
+        const bool ok = kin && m < g.M && xr >= 0 && xr < T_valid;
         const int xc = xr < 0 ? 0 : (xr < g.T_in ? xr : g.T_in - 1);
         ra[ch][i] = *reinterpret_cast<const float4*>(X + (int64_t)xc * g.ldx + c0);
         amask |= (ok ? 1u : 0u) << (ch * 8 + i);

@@ -82,31 +82,36 @@ __global__ __launch_bounds__(256) void flow_spks(const float* __restrict__ emb, 
   }
 }
 
-// static 240 columns of the estimator input: hin[0][t] = [ . | mu[t] | spks | cond[t] ], hin[1][t] = [ . | 0 | 0 | 0 ]; cond[t] =
-// prompt_feat[t] for t < m1, else 0; and x = z^T into columns 0..79 of both halves.
+// static 240 columns of the estimator input of ONE utterance: hin[0][t] = [ . | mu[t] | spks | cond[t] ], hin[1][t] = [ . | 0 | 0 | 0 ];
+// cond[t] = prompt_feat[t] for t < m1, else 0; and x = z^T into columns 0..79 of both halves.  The utterance owns `rows` >= T rows per
+// half (stacked, padded batch): rows T .. rows-1 are written as zeros, so every row of the stack is defined.
 __global__ __launch_bounds__(256) void flow_pack_inputs(const float* __restrict__ z, const float* __restrict__ mu, const float* __restrict__ spks,
                                                         const float* __restrict__ pf, float* __restrict__ hin, float* __restrict__ x, int T, int M,
-                                                        int m1) {
+                                                        int m1, int rows) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)T * M) return;
+  if (e >= (int64_t)rows * M) return;
   const int t = (int)(e / M), c = (int)(e % M);
   const int64_t ld = 4 * M;
   float* r0 = hin + (int64_t)t * ld;
-  float* r1 = hin + ((int64_t)T + t) * ld;
-  const float xv = z[(int64_t)c * T + t];
+  float* r1 = hin + ((int64_t)rows + t) * ld;
+  const bool in = t < T;
+  const float xv = in ? z[(int64_t)c * T + t] : 0.f;
   x[(int64_t)t * M + c] = xv;
   r0[c] = xv; r1[c] = xv;
-  r0[M + c] = mu[(int64_t)t * M + c]; r1[M + c] = 0.f;
-  r0[2 * M + c] = spks[c]; r1[2 * M + c] = 0.f;
+  r0[M + c] = in ? mu[(int64_t)t * M + c] : 0.f; r1[M + c] = 0.f;
+  r0[2 * M + c] = in ? spks[c] : 0.f; r1[2 * M + c] = 0.f;
   r0[3 * M + c] = t < m1 ? pf[(int64_t)t * M + c] : 0.f; r1[3 * M + c] = 0.f;
 }
 
-// x += dt ((1 + r) d_cond - r d_uncond), mirrored into columns 0..79 of both halves of hin   (CosyVoice2CFM.swift:166-176)
+// x += dt ((1 + r) d_cond - r d_uncond), mirrored into columns 0..79 of both halves of hin   (CosyVoice2CFM.swift:166-176);
+// blockIdx.y = utterance: d / hin hold [cond | uncond] halves of T rows each per utterance, x holds T rows per utterance
 __global__ __launch_bounds__(256) void flow_euler(const float* __restrict__ d, float* __restrict__ x, float* __restrict__ hin, int T, int M,
                                                   float dt, float rate) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (int64_t)T * M) return;
   const int t = (int)(e / M), c = (int)(e % M);
+  const int64_t u = blockIdx.y;
+  d += u * 2 * T * M; hin += u * 2 * T * 4 * M; x += u * T * M;
   const float dc = d[(int64_t)t * M + c], du = d[((int64_t)T + t) * M + c];
   const float comb = (1.0f + rate) * dc - rate * du;
   const float xv = x[e] + dt * comb;
@@ -273,12 +278,12 @@ struct Run {
   // Y[M][N] = act(X[M][K*taps] W^T + b) (+ R); taps > 1: window starting `pad` rows back (zero outside the sequence); nseq > 1: X / Y / R
   // are nseq stacked sequences of M rows each, convolved independently (one grid.z phase per sequence)
   bool gemm(const Lin& l, const float* X, int64_t ldx, int M, float* Y, int64_t ldy, int act = 0, const float* R = nullptr, int pad = 0,
-            int nseq = 1) {
+            int nseq = 1, const int32_t* phase_len = nullptr) {
     if (rc != MIA_OK) return false;
     ConvGemmArgs g;
     g.X = X; g.ldx = ldx; g.T_in = M; g.W = l.w; g.bias = l.b; g.Y = Y; g.ldy = ldy; g.T_out = M * nseq; g.R = R; g.ldr = ldy;
     g.M = M; g.N = l.N; g.Cin = l.K; g.taps = l.taps; g.pad = pad; g.gelu = act;
-    if (nseq > 1) { g.x_phase_step = M; g.y_phase_step = M; }
+    if (nseq > 1) { g.x_phase_step = M; g.y_phase_step = M; g.phase_len = phase_len; }
     if (const char* e = codec_conv_gemm_check(g)) return fail(MIA_ERR_INVALID_ARGUMENT, e);
     if (codec_conv_gemm_launch(g, nseq, s)) return fail(MIA_ERR_DEVICE, "gemm launch failed");
     return true;
@@ -306,7 +311,8 @@ struct Bufs {
   float *hin, *xs, *c1, *h1, *xr, *att2, *d, *tsin, *te1, *te2, *tm, *tpr, *out, *xr2, *cat;  // estimator side
 };
 
-size_t carve(mia_flow* f, int Tt, int T, int S, Bufs* b) {
+// T = rows of the (stacked) encoder output: U utterances x the longest one's frames
+size_t carve(mia_flow* f, int Tt, int T, int S, Bufs* b, int U = 1) {
   const mia_flow_config& c = f->cfg;
   const size_t D = c.input_size, FF = c.enc_linear_units, M = c.output_size, C = c.dec_channels, inner = (size_t)c.dec_heads * 64;
   const size_t TE = 4 * C;
@@ -314,7 +320,7 @@ size_t carve(mia_flow* f, int Tt, int T, int S, Bufs* b) {
   const size_t T2 = 2 * (size_t)T;
   size_t sizes[] = {
       al((size_t)T * D), al((size_t)T * D), al((size_t)T * D), al((size_t)T * 3 * D), al((size_t)T * D), al((size_t)T * D), al((size_t)T * FF),
-      al((size_t)T * D), al((size_t)T * M), al(M), al((size_t)T * M), al((size_t)T * M), al(c.spk_embed_dim),
+      al((size_t)T * D), al((size_t)T * M), al((size_t)U * M), al((size_t)T * M), al((size_t)T * M), al((size_t)U * c.spk_embed_dim),
       al(T2 * 4 * M), al((size_t)T * M), al(T2 * C), al(T2 * std::max(std::max(3 * inner, 4 * C), 2 * C)), al(T2 * C), al(T2 * inner), al(T2 * M),
       al((size_t)S * c.dec_in_channels), al((size_t)S * TE), al((size_t)S * TE), al((size_t)S * TE), al((size_t)S * f->n_res * C), al((size_t)T * M),
       al(T2 * C), al(T2 * 2 * C)};
@@ -329,69 +335,73 @@ size_t carve(mia_flow* f, int Tt, int T, int S, Bufs* b) {
   return tot;
 }
 
-// one ConformerEncoderLayer (ConformerEncoderLayer.swift:69-165): pre-norm rel-pos MHA + pre-norm SiLU FFN
-void conformer_layer(Run& r, const ConfLayer& l, Bufs& b, int T, int D, int H, int FF, int chunk = 0) {
-  r.ln(l.n_mha, b.x, b.h, T, D, 1e-12f);
-  r.gemm(l.qkv, b.h, D, T, b.qkv, 3 * D);
+// one ConformerEncoderLayer (ConformerEncoderLayer.swift:69-165): pre-norm rel-pos MHA + pre-norm SiLU FFN, on U stacked sequences of
+// T rows each (len: their valid rows on the device, null when U == 1)
+void conformer_layer(Run& r, const ConfLayer& l, Bufs& b, int T, int D, int H, int FF, int chunk = 0, int U = 1, const int32_t* len = nullptr) {
+  const int R = U * T;
+  r.ln(l.n_mha, b.x, b.h, R, D, 1e-12f);
+  r.gemm(l.qkv, b.h, D, R, b.qkv, 3 * D);
   r.gemm(l.pos, b.pe, D, T, b.pb, D);
   AttnF32Args a;
   a.q = b.qkv; a.ldq = 3 * D; a.k = b.qkv + D; a.ldk = 3 * D; a.v = b.qkv + 2 * D; a.ldv = 3 * D; a.p = b.pb; a.ldp = D;
-  a.bias_u = l.u; a.bias_v = l.v; a.out = b.att; a.ldo = D; a.B = 1; a.T = T; a.H = H; a.scale = 1.0f / sqrtf((float)(D / H));
-  a.chunk = chunk;
+  a.bias_u = l.u; a.bias_v = l.v; a.out = b.att; a.ldo = D; a.B = U; a.T = T; a.H = H; a.scale = 1.0f / sqrtf((float)(D / H));
+  a.chunk = chunk; a.seq_len = len;
   r.attn(a);
-  r.gemm(l.out, b.att, D, T, b.x, D, 0, b.x);
-  r.ln(l.n_ff, b.x, b.h, T, D, 1e-12f);
-  r.gemm(l.ff1, b.h, D, T, b.g, FF, 4);
-  r.gemm(l.ff2, b.g, FF, T, b.x, D, 0, b.x);
+  r.gemm(l.out, b.att, D, R, b.x, D, 0, b.x);
+  r.ln(l.n_ff, b.x, b.h, R, D, 1e-12f);
+  r.gemm(l.ff1, b.h, D, R, b.g, FF, 4);
+  r.gemm(l.ff2, b.g, FF, R, b.x, D, 0, b.x);
 }
 
-// tokens (device) -> mu [T][80]
-int run_encoder(mia_flow* f, Bufs& b, const int32_t* d_ids, int Tt, int chunk = 0) {
+// tokens (device, U stacked sequences of Tt ids each, padded) -> mu [U][T][80]; len_tok / len_up: valid tokens / frames per sequence
+int run_encoder(mia_flow* f, Bufs& b, const int32_t* d_ids, int Tt, int chunk = 0, int U = 1, const int32_t* len_tok = nullptr,
+                const int32_t* len_up = nullptr) {
   const mia_flow_config& c = f->cfg;
   const int D = c.input_size, H = c.enc_heads, FF = c.enc_linear_units, st = c.upsample_stride, T = Tt * st;
+  const int Rt = U * Tt, R = U * T;
   Run r{f, f->ctx->stream};
   hipStream_t s = r.s;
-  hipLaunchKernelGGL(flow_gather, dim3((unsigned)(((int64_t)Tt * (D / 4) + 255) / 256)), dim3(256), 0, s, d_ids, f->emb_table, b.x0, Tt, D, c.vocab_size);
+  hipLaunchKernelGGL(flow_gather, dim3((unsigned)(((int64_t)Rt * (D / 4) + 255) / 256)), dim3(256), 0, s, d_ids, f->emb_table, b.x0, Rt, D, c.vocab_size);
   hipLaunchKernelGGL(flow_sinusoid, dim3((unsigned)(((int64_t)T * (D / 2) + 255) / 256)), dim3(256), 0, s, b.pe, T, D, -logf(10000.0f) / (float)D);
   // LinearNoSubsampling: linear -> LayerNorm(1e-5) -> * sqrt(D) (folded into the norm's affine)
-  r.gemm(f->embed, b.x0, D, Tt, b.h, D);
-  r.ln(f->embed_n, b.h, b.x0, Tt, D, 1e-5f);
-  // PreLookaheadLayer: conv1 over x[t .. t+L] (zero beyond the end) -> leaky-ReLU -> causal conv2 (k 3) -> + x
-  r.gemm(f->pl1, b.x0, D, Tt, b.h, D, 5, nullptr, 0);
-  r.gemm(f->pl2, b.h, D, Tt, b.x, D, 0, b.x0, 2);
-  for (const ConfLayer& l : f->enc) conformer_layer(r, l, b, Tt, D, H, FF, chunk);
+  r.gemm(f->embed, b.x0, D, Rt, b.h, D);
+  r.ln(f->embed_n, b.h, b.x0, Rt, D, 1e-5f);
+  // PreLookaheadLayer: conv1 over x[t .. t+L] (zero beyond the sequence's end) -> leaky-ReLU -> causal conv2 (k 3) -> + x
+  r.gemm(f->pl1, b.x0, D, Tt, b.h, D, 5, nullptr, 0, U, len_tok);
+  r.gemm(f->pl2, b.h, D, Tt, b.x, D, 0, b.x0, 2, U);
+  for (const ConfLayer& l : f->enc) conformer_layer(r, l, b, Tt, D, H, FF, chunk, U, len_tok);
   // Upsample1D: nearest repeat x stride, left pad 2 stride, conv k = 2 stride + 1
-  hipLaunchKernelGGL(flow_repeat_rows, dim3((unsigned)(((int64_t)T * (D / 4) + 255) / 256)), dim3(256), 0, s, b.x, b.att, T, D, st);
-  r.gemm(f->up_conv, b.att, D, T, b.h, D, 0, nullptr, 2 * st);
-  r.gemm(f->up_embed, b.h, D, T, b.x0, D);
-  r.ln(f->up_embed_n, b.x0, b.x, T, D, 1e-5f);
-  for (const ConfLayer& l : f->up_enc) conformer_layer(r, l, b, T, D, H, FF, chunk * st);      // effectiveUpChunkSize (:452)
-  r.ln(f->after_n, b.x, b.h, T, D, 1e-5f);
-  r.gemm(f->enc_proj, b.h, D, T, b.mu, c.output_size);
+  hipLaunchKernelGGL(flow_repeat_rows, dim3((unsigned)(((int64_t)R * (D / 4) + 255) / 256)), dim3(256), 0, s, b.x, b.att, R, D, st);
+  r.gemm(f->up_conv, b.att, D, T, b.h, D, 0, nullptr, 2 * st, U);
+  r.gemm(f->up_embed, b.h, D, R, b.x0, D);
+  r.ln(f->up_embed_n, b.x0, b.x, R, D, 1e-5f);
+  for (const ConfLayer& l : f->up_enc) conformer_layer(r, l, b, T, D, H, FF, chunk * st, U, len_up);      // effectiveUpChunkSize (:452)
+  r.ln(f->after_n, b.x, b.h, R, D, 1e-5f);
+  r.gemm(f->enc_proj, b.h, D, R, b.mu, c.output_size);
   if (r.rc == MIA_OK && hipGetLastError() != hipSuccess) return mia_fail(f->ctx, MIA_ERR_DEVICE, "flow: encoder launch failed");
   return r.rc;
 }
 
-// CausalResnetBlock1D (S3GenDecoder.swift:89-101) on the stacked pair X [2 T][Cin] -> Y [2 T][C]  (Y must not alias X)
-void resnet(Run& r, const Resnet& rn, Bufs& b, const float* X, int Cin, int T, int C, const float* tvec, float* Y) {
-  const int M = 2 * T;
-  r.gemm(rn.c1, X, Cin, T, b.c1, C, 0, nullptr, 2, 2);
+// CausalResnetBlock1D (S3GenDecoder.swift:89-101) on ns stacked sequences of T rows: X [ns T][Cin] -> Y [ns T][C]  (Y must not alias X)
+void resnet(Run& r, const Resnet& rn, Bufs& b, const float* X, int Cin, int T, int C, const float* tvec, float* Y, int ns = 2) {
+  const int M = ns * T;
+  r.gemm(rn.c1, X, Cin, T, b.c1, C, 0, nullptr, 2, ns);
   r.ln_mish(rn.n1, b.c1, tvec + (size_t)rn.idx * C, b.h1, M, C);
-  r.gemm(rn.c2, b.h1, C, T, b.c1, C, 0, nullptr, 2, 2);
+  r.gemm(rn.c2, b.h1, C, T, b.c1, C, 0, nullptr, 2, ns);
   r.ln_mish(rn.n2, b.c1, nullptr, b.h1, M, C);
   r.gemm(rn.res, X, Cin, M, Y, C, 0, b.h1);
 }
 
-// BasicTransformerBlock (MatchaTransformer.swift:128-146) in place on x [2 T][C]
-void tblock(Run& r, const TBlock& t, Bufs& b, float* x, int T, int C, int H, int chunk = 0) {
-  const int M = 2 * T, inner = H * 64;
+// BasicTransformerBlock (MatchaTransformer.swift:128-146) in place on x [ns T][C]; len: valid rows per sequence (device) or null
+void tblock(Run& r, const TBlock& t, Bufs& b, float* x, int T, int C, int H, int chunk = 0, int ns = 2, const int32_t* len = nullptr) {
+  const int M = ns * T, inner = H * 64;
   float* h = b.c1;          // [M][C] scratch
   float* big = b.h1;        // [M][max(3 inner, 4 C)] scratch
   r.ln(t.n1, x, h, M, C, 1e-5f);
   r.gemm(t.qkv, h, C, M, big, 3 * inner);
   AttnF32Args a;
   a.q = big; a.ldq = 3 * inner; a.k = big + inner; a.ldk = 3 * inner; a.v = big + 2 * inner; a.ldv = 3 * inner;
-  a.out = b.att2; a.ldo = inner; a.B = 2; a.T = T; a.H = H; a.scale = 0.125f; a.chunk = chunk;
+  a.out = b.att2; a.ldo = inner; a.B = ns; a.T = T; a.H = H; a.scale = 0.125f; a.chunk = chunk; a.seq_len = len;
   r.attn(a);
   r.gemm(t.out, b.att2, inner, M, x, C, 0, x);
   r.ln(t.n3, x, h, M, C, 1e-5f);
@@ -460,9 +470,10 @@ void mia_flow_free(mia_flow* f) {
   delete f;
 }
 
-static int flow_prepare(mia_flow* f, int Tt, int S, Bufs& b) {
+// scratch for U stacked utterances of at most Tt tokens; the id buffer also holds the 4 U per-sequence lengths behind the ids
+static int flow_prepare(mia_flow* f, int Tt, int S, Bufs& b, int U = 1) {
   const int T = Tt * f->cfg.upsample_stride;
-  const size_t need = carve(f, Tt, T, S, nullptr);
+  const size_t need = carve(f, Tt, U * T, S, nullptr, U);
   if (need > f->arena_floats) {
     MIA_HIP(f->ctx, hipStreamSynchronize(f->ctx->stream));
     if (f->arena) (void)hipFree(f->arena);
@@ -470,21 +481,22 @@ static int flow_prepare(mia_flow* f, int Tt, int S, Bufs& b) {
     if (hipMalloc((void**)&f->arena, need * 4) != hipSuccess) return mia_fail(f->ctx, MIA_ERR_OUT_OF_MEMORY, "flow: scratch hipMalloc failed");
     f->arena_floats = need;
   }
-  carve(f, Tt, T, S, &b);
-  if ((size_t)Tt > f->ids_cap) {
+  carve(f, Tt, U * T, S, &b, U);
+  const size_t ids = (size_t)U * Tt + 4 * (size_t)U;
+  if (ids > f->ids_cap) {
     MIA_HIP(f->ctx, hipStreamSynchronize(f->ctx->stream));
     if (f->d_ids) (void)hipFree(f->d_ids);
     f->d_ids = nullptr; f->ids_cap = 0;
-    if (hipMalloc((void**)&f->d_ids, (size_t)Tt * 4 + 64) != hipSuccess) return mia_fail(f->ctx, MIA_ERR_OUT_OF_MEMORY, "flow: hipMalloc failed");
-    f->ids_cap = Tt;
+    if (hipMalloc((void**)&f->d_ids, ids * 4 + 64) != hipSuccess) return mia_fail(f->ctx, MIA_ERR_OUT_OF_MEMORY, "flow: hipMalloc failed");
+    f->ids_cap = ids;
   }
   return MIA_OK;
 }
 
-static int upload_tokens(mia_flow* f, const int32_t* prompt_token, int n_prompt, const int32_t* token, int n_token, int mem) {
+static int upload_tokens(mia_flow* f, int32_t* dst, const int32_t* prompt_token, int n_prompt, const int32_t* token, int n_token, int mem) {
   const hipMemcpyKind kind = mem == MIA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  if (n_prompt) MIA_HIP(f->ctx, hipMemcpyAsync(f->d_ids, prompt_token, (size_t)n_prompt * 4, kind, f->ctx->stream));
-  MIA_HIP(f->ctx, hipMemcpyAsync(f->d_ids + n_prompt, token, (size_t)n_token * 4, kind, f->ctx->stream));
+  if (n_prompt) MIA_HIP(f->ctx, hipMemcpyAsync(dst, prompt_token, (size_t)n_prompt * 4, kind, f->ctx->stream));
+  MIA_HIP(f->ctx, hipMemcpyAsync(dst + n_prompt, token, (size_t)n_token * 4, kind, f->ctx->stream));
   return MIA_OK;
 }
 
@@ -494,7 +506,7 @@ int mia_flow_encode(mia_flow* f, const int32_t* token, int n_token, float* mu, i
   MIA_HIP(f->ctx, hipSetDevice(f->ctx->device));
   Bufs b;
   if (int rc = flow_prepare(f, n_token, 1, b)) return rc;
-  if (int rc = upload_tokens(f, nullptr, 0, token, n_token, mem)) return rc;
+  if (int rc = upload_tokens(f, f->d_ids, nullptr, 0, token, n_token, mem)) return rc;
   if (int rc = run_encoder(f, b, f->d_ids, n_token)) return rc;
   const size_t n = (size_t)n_token * f->cfg.upsample_stride * f->cfg.output_size;
   MIA_HIP(f->ctx, hipMemcpyAsync(mu, b.mu, n * 4, mem == MIA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, f->ctx->stream));
@@ -502,36 +514,73 @@ int mia_flow_encode(mia_flow* f, const int32_t* token, int n_token, float* mu, i
   return MIA_OK;
 }
 
+// One utterance of a flow call (all pointers host or device per `mem`)
+struct FlowUtt {
+  const int32_t* token; int n_token; const int32_t* prompt_token; int n_prompt; const float* prompt_feat; int prompt_feat_len;
+  const float* embedding; const float* z; float* mel; int* mel_frames;
+};
+
+// U utterances side by side: every stage runs once on the stack of U (x 2 for the estimator's cond / uncond pair) sequences, each padded
+// to the longest one's length.  Padding never reaches a valid row: the convolutions are causal except the encoder's look-ahead window
+// (per-sequence zero beyond the end, ConvGemmArgs::phase_len), attention masks the keys past a sequence's own length
+// (AttnF32Args::seq_len), everything else is row-wise -- so an utterance's mel equals its own single call bit for bit (asserted in
+// tests/test_flow_gpu.py).  With U == 1 no length array is passed and the launches are exactly the single-utterance ones.
 // finalize = 0 drops the encoder's last pre_lookahead_len * upsample_stride frames (CosyVoice2Model.swift:504-510); enc_chunk / dec_chunk > 0
 // switch the conformer encoder / the estimator's transformer blocks to their chunk-masked "streaming" attention
-static int flow_inference_impl(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
-                               int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, int finalize, int enc_chunk, int dec_chunk,
-                               float* mel, int* mel_frames, int mem) {
+static int flow_inference_core(mia_flow* f, const FlowUtt* utt, int U, int n_timesteps, int finalize, int enc_chunk, int dec_chunk, int mem) {
   if (!f) return MIA_ERR_MODEL_NOT_LOADED;
   mia_ctx* ctx = f->ctx;
   const mia_flow_config& c = f->cfg;
-  MIA_CHECK_ARG(ctx, token && embedding && z && mel && n_token > 0 && n_prompt >= 0 && (n_prompt == 0 || prompt_token) &&
-                         (mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE), "flow_inference: bad argument");
+  MIA_CHECK_ARG(ctx, utt && U >= 1 && U <= 64 && (mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE), "flow_inference: bad argument (1..64 utterances)");
   const int S = n_timesteps > 0 ? n_timesteps : c.n_timesteps;
-  const int Tt = n_token + n_prompt, T_enc = Tt * c.upsample_stride, M = c.output_size, C = c.dec_channels, H = c.dec_heads;
-  const int trim = finalize ? 0 : c.pre_lookahead_len * c.upsample_stride;
-  const int T = T_enc > trim ? T_enc - trim : T_enc;       // (the reference trims only when something is left, :507)
-  MIA_CHECK_ARG(ctx, Tt <= 4096 && S <= 1000, "flow_inference: at most 4096 tokens and 1000 steps");
-  MIA_CHECK_ARG(ctx, enc_chunk >= 0 && dec_chunk >= 0, "flow_inference: negative chunk size");
-  MIA_CHECK_ARG(ctx, prompt_feat_len >= 0 && prompt_feat_len < T && (prompt_feat_len == 0 || prompt_feat), "flow_inference: prompt_feat_len must be in [0, %d)", T);
+  const int st = c.upsample_stride, M = c.output_size, C = c.dec_channels, H = c.dec_heads;
+  const int trim = finalize ? 0 : c.pre_lookahead_len * st;
+  MIA_CHECK_ARG(ctx, S <= 1000 && enc_chunk >= 0 && dec_chunk >= 0, "flow_inference: at most 1000 steps, chunk sizes >= 0");
+  int Tt = 0;                                  // longest token sequence
+  std::vector<int32_t> lens((size_t)4 * U);    // [tokens | encoder frames | estimator frames of the cond, uncond sequences]
+  std::vector<int> Tu(U);
+  for (int u = 0; u < U; ++u) {
+    const FlowUtt& q = utt[u];
+    MIA_CHECK_ARG(ctx, q.token && q.embedding && q.z && q.mel && q.n_token > 0 && q.n_prompt >= 0 && (q.n_prompt == 0 || q.prompt_token),
+                  "flow_inference: utterance %d: bad argument", u);
+    const int tt = q.n_token + q.n_prompt, te = tt * st;
+    MIA_CHECK_ARG(ctx, tt <= 4096, "flow_inference: at most 4096 tokens");
+    Tu[u] = te > trim ? te - trim : te;       // (the reference trims only when something is left, :507)
+    MIA_CHECK_ARG(ctx, q.prompt_feat_len >= 0 && q.prompt_feat_len < Tu[u] && (q.prompt_feat_len == 0 || q.prompt_feat),
+                  "flow_inference: utterance %d: prompt_feat_len must be in [0, %d)", u, Tu[u]);
+    lens[u] = tt; lens[U + u] = te; lens[2 * U + 2 * u] = Tu[u]; lens[2 * U + 2 * u + 1] = Tu[u];
+    Tt = std::max(Tt, tt);
+  }
+  const int T_enc = Tt * st;
+  const int T = T_enc > trim ? T_enc - trim : T_enc;      // rows per sequence of the estimator's stack
+  MIA_CHECK_ARG(ctx, (int64_t)2 * U * T_enc * std::max(4 * C, 4 * M) < (int64_t)1 << 31, "flow_inference: batch too large");
   MIA_HIP(ctx, hipSetDevice(ctx->device));
   Bufs b;
-  if (int rc = flow_prepare(f, Tt, S, b)) return rc;
+  if (int rc = flow_prepare(f, Tt, S, b, U)) return rc;
   hipStream_t s = ctx->stream;
   const hipMemcpyKind kind = mem == MIA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  if (int rc = upload_tokens(f, prompt_token, n_prompt, token, n_token, mem)) return rc;
-  MIA_HIP(ctx, hipMemcpyAsync(b.emb, embedding, (size_t)c.spk_embed_dim * 4, kind, s));
-  MIA_HIP(ctx, hipMemcpyAsync(b.z, z, (size_t)T * M * 4, kind, s));
-  if (prompt_feat_len) MIA_HIP(ctx, hipMemcpyAsync(b.pf, prompt_feat, (size_t)prompt_feat_len * M * 4, kind, s));
-  if (int rc = run_encoder(f, b, f->d_ids, Tt, enc_chunk)) return rc;
-  hipLaunchKernelGGL(flow_spks, dim3(1), dim3(256), 0, s, b.emb, f->spk.w, f->spk.b, b.spks, c.spk_embed_dim, M);
+  int32_t* d_len = f->d_ids + (size_t)U * Tt;
+  if (U > 1) {
+    MIA_HIP(ctx, hipMemsetAsync(f->d_ids, 0, (size_t)U * Tt * 4, s));     // padding ids: a valid table row
+    MIA_HIP(ctx, hipMemcpyAsync(d_len, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, s));
+  }
+  for (int u = 0; u < U; ++u) {
+    const FlowUtt& q = utt[u];
+    if (int rc = upload_tokens(f, f->d_ids + (size_t)u * Tt, q.prompt_token, q.n_prompt, q.token, q.n_token, mem)) return rc;
+    MIA_HIP(ctx, hipMemcpyAsync(b.emb + (size_t)u * c.spk_embed_dim, q.embedding, (size_t)c.spk_embed_dim * 4, kind, s));
+    MIA_HIP(ctx, hipMemcpyAsync(b.z + (size_t)u * T * M, q.z, (size_t)Tu[u] * M * 4, kind, s));
+    if (q.prompt_feat_len) MIA_HIP(ctx, hipMemcpyAsync(b.pf + (size_t)u * T * M, q.prompt_feat, (size_t)q.prompt_feat_len * M * 4, kind, s));
+  }
+  const int32_t* len_tok = U > 1 ? d_len : nullptr;
+  const int32_t* len_up = U > 1 ? d_len + U : nullptr;
+  const int32_t* len_est = U > 1 ? d_len + 2 * U : nullptr;
+  if (int rc = run_encoder(f, b, f->d_ids, Tt, enc_chunk, U, len_tok, len_up)) return rc;
   const unsigned gTM = (unsigned)(((int64_t)T * M + 255) / 256);
-  hipLaunchKernelGGL(flow_pack_inputs, dim3(gTM), dim3(256), 0, s, b.z, b.mu, b.spks, b.pf, b.hin, b.xs, T, M, prompt_feat_len);
+  for (int u = 0; u < U; ++u) {
+    hipLaunchKernelGGL(flow_spks, dim3(1), dim3(256), 0, s, b.emb + (size_t)u * c.spk_embed_dim, f->spk.w, f->spk.b, b.spks + (size_t)u * M, c.spk_embed_dim, M);
+    hipLaunchKernelGGL(flow_pack_inputs, dim3(gTM), dim3(256), 0, s, b.z + (size_t)u * T * M, b.mu + (size_t)u * T_enc * M, b.spks + (size_t)u * M,
+                       b.pf + (size_t)u * T * M, b.hin + (size_t)u * 2 * T * 4 * M, b.xs + (size_t)u * T * M, Tu[u], M, utt[u].prompt_feat_len, T);
+  }
 
   // ---- time grid (cosine schedule) and time embeddings of every step, in float32 like the reference (CosyVoice2CFM.swift:89-92,127-181)
   std::vector<float> tspan(S + 1), tval(S), dts(S);
@@ -541,70 +590,93 @@ static int flow_inference_impl(mia_flow* f, const int32_t* token, int n_token, c
   }
   {
     float t = tspan[0], dt = tspan[1] - tspan[0];
-    for (int st = 1; st <= S; ++st) {
-      tval[st - 1] = t; dts[st - 1] = dt;
+    for (int k = 1; k <= S; ++k) {
+      tval[k - 1] = t; dts[k - 1] = dt;
       t = t + dt;
-      if (st < S) dt = tspan[st + 1] - t;
+      if (k < S) dt = tspan[k + 1] - t;
     }
   }
   const int IC = c.dec_in_channels, half = IC / 2, TE = 4 * C;
   std::vector<float> tsin((size_t)S * IC);
   const float emb_scale = logf(10000.0f) / (float)(half - 1);
-  for (int st = 0; st < S; ++st)
+  for (int k = 0; k < S; ++k)
     for (int i = 0; i < half; ++i) {
-      const float arg = 1000.0f * tval[st] * expf((float)i * -emb_scale);
-      tsin[(size_t)st * IC + i] = sinf(arg);
-      tsin[(size_t)st * IC + half + i] = cosf(arg);
+      const float arg = 1000.0f * tval[k] * expf((float)i * -emb_scale);
+      tsin[(size_t)k * IC + i] = sinf(arg);
+      tsin[(size_t)k * IC + half + i] = cosf(arg);
     }
   MIA_HIP(ctx, hipMemcpyAsync(b.tsin, tsin.data(), tsin.size() * 4, hipMemcpyHostToDevice, s));
-  MIA_HIP(ctx, hipStreamSynchronize(s));    // tsin is a stack-lifetime host buffer
+  MIA_HIP(ctx, hipStreamSynchronize(s));    // tsin / lens are stack-lifetime host buffers
   Run r{f, s};
   r.gemm(f->t1, b.tsin, IC, S, b.te1, TE, 4);
   r.gemm(f->t2, b.te1, TE, S, b.te2, TE);
   hipLaunchKernelGGL(flow_mish, dim3((unsigned)(((int64_t)S * TE + 255) / 256)), dim3(256), 0, s, b.te2, b.tm, (int64_t)S * TE);
   r.gemm(f->tproj, b.tm, TE, S, b.tpr, f->n_res * C);
 
-  const int M2 = 2 * T;
-  for (int st = 0; st < S && r.rc == MIA_OK; ++st) {
-    const float* tvec = b.tpr + (size_t)st * f->n_res * C;
+  const int ns = 2 * U, M2 = ns * T;        // the stack: [cond, uncond] of every utterance, T rows each
+  for (int k = 0; k < S && r.rc == MIA_OK; ++k) {
+    const float* tvec = b.tpr + (size_t)k * f->n_res * C;
     // down block
-    resnet(r, f->down.rn, b, b.hin, IC, T, C, tvec, b.xr);
-    for (const TBlock& t : f->down.tb) tblock(r, t, b, b.xr, T, C, H, dec_chunk);
+    resnet(r, f->down.rn, b, b.hin, IC, T, C, tvec, b.xr, ns);
+    for (const TBlock& t : f->down.tb) tblock(r, t, b, b.xr, T, C, H, dec_chunk, ns, len_est);
     // skip -> right half of the up block's input; causal "downsample" conv (stride 1 for the single-level U-Net)
     MIA_HIP(ctx, hipMemcpy2DAsync(b.cat + C, (size_t)2 * C * 4, b.xr, (size_t)C * 4, (size_t)C * 4, M2, hipMemcpyDeviceToDevice, s));
     float* cur = b.xr2; float* nxt = b.xr;
-    r.gemm(f->down_conv, b.xr, C, T, cur, C, 0, nullptr, 2, 2);
+    r.gemm(f->down_conv, b.xr, C, T, cur, C, 0, nullptr, 2, ns);
     for (const UBlock& mb : f->mid) {
-      resnet(r, mb.rn, b, cur, C, T, C, tvec, nxt);
-      for (const TBlock& t : mb.tb) tblock(r, t, b, nxt, T, C, H, dec_chunk);
+      resnet(r, mb.rn, b, cur, C, T, C, tvec, nxt, ns);
+      for (const TBlock& t : mb.tb) tblock(r, t, b, nxt, T, C, H, dec_chunk, ns, len_est);
       std::swap(cur, nxt);
     }
     MIA_HIP(ctx, hipMemcpy2DAsync(b.cat, (size_t)2 * C * 4, cur, (size_t)C * 4, (size_t)C * 4, M2, hipMemcpyDeviceToDevice, s));
-    resnet(r, f->up.rn, b, b.cat, 2 * C, T, C, tvec, nxt);
-    for (const TBlock& t : f->up.tb) tblock(r, t, b, nxt, T, C, H, dec_chunk);
-    r.gemm(f->up_conv2, nxt, C, T, cur, C, 0, nullptr, 2, 2);
+    resnet(r, f->up.rn, b, b.cat, 2 * C, T, C, tvec, nxt, ns);
+    for (const TBlock& t : f->up.tb) tblock(r, t, b, nxt, T, C, H, dec_chunk, ns, len_est);
+    r.gemm(f->up_conv2, nxt, C, T, cur, C, 0, nullptr, 2, ns);
     // final block + projection
-    r.gemm(f->final_conv, cur, C, T, b.c1, C, 0, nullptr, 2, 2);
+    r.gemm(f->final_conv, cur, C, T, b.c1, C, 0, nullptr, 2, ns);
     r.ln_mish(f->final_n, b.c1, nullptr, b.h1, M2, C);
     r.gemm(f->final_proj, b.h1, C, M2, b.d, M);
-    hipLaunchKernelGGL(flow_euler, dim3(gTM), dim3(256), 0, s, b.d, b.xs, b.hin, T, M, dts[st], c.cfg_rate);
+    hipLaunchKernelGGL(flow_euler, dim3(gTM, U), dim3(256), 0, s, b.d, b.xs, b.hin, T, M, dts[k], c.cfg_rate);
   }
   if (r.rc != MIA_OK) return r.rc;
-  const int To = T - prompt_feat_len;
-  if (mel_frames) *mel_frames = To;
-  float* dst = mem == MIA_MEM_DEVICE ? mel : b.out;
-  hipLaunchKernelGGL(flow_emit, dim3((unsigned)(((int64_t)To * M + 255) / 256)), dim3(256), 0, s, b.xs, dst, T, M, prompt_feat_len);
-  MIA_HIP(ctx, hipGetLastError());
-  if (mem == MIA_MEM_HOST) {
-    MIA_HIP(ctx, hipMemcpyAsync(mel, b.out, (size_t)To * M * 4, hipMemcpyDeviceToHost, s));
-    MIA_HIP(ctx, hipStreamSynchronize(s));
+  size_t out_off = 0;
+  for (int u = 0; u < U; ++u) {
+    const int To = Tu[u] - utt[u].prompt_feat_len;
+    if (utt[u].mel_frames) *utt[u].mel_frames = To;
+    float* dst = mem == MIA_MEM_DEVICE ? utt[u].mel : b.out + out_off;
+    hipLaunchKernelGGL(flow_emit, dim3((unsigned)(((int64_t)To * M + 255) / 256)), dim3(256), 0, s, b.xs + (size_t)u * T * M, dst, Tu[u], M, utt[u].prompt_feat_len);
+    if (mem == MIA_MEM_HOST) MIA_HIP(ctx, hipMemcpyAsync(utt[u].mel, dst, (size_t)To * M * 4, hipMemcpyDeviceToHost, s));
+    out_off += (size_t)To * M;
   }
+  MIA_HIP(ctx, hipGetLastError());
+  if (mem == MIA_MEM_HOST) MIA_HIP(ctx, hipStreamSynchronize(s));
   return MIA_OK;
+}
+
+static int flow_inference_impl(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
+                               int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, int finalize, int enc_chunk, int dec_chunk,
+                               float* mel, int* mel_frames, int mem) {
+  if (!f) return MIA_ERR_MODEL_NOT_LOADED;
+  const FlowUtt u{token, n_token, prompt_token, n_prompt, prompt_feat, prompt_feat_len, embedding, z, mel, mel_frames};
+  return flow_inference_core(f, &u, 1, n_timesteps, finalize, enc_chunk, dec_chunk, mem);
 }
 
 int mia_flow_inference(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,
                        int prompt_feat_len, const float* embedding, const float* z, int n_timesteps, float* mel, int mem) {
   return flow_inference_impl(f, token, n_token, prompt_token, n_prompt, prompt_feat, prompt_feat_len, embedding, z, n_timesteps, 1, 0, 0, mel, nullptr, mem);
+}
+
+int mia_flow_inference_batch(mia_flow* f, int n_utt, const int32_t* const* token, const int32_t* n_token, const int32_t* const* prompt_token,
+                             const int32_t* n_prompt, const float* const* prompt_feat, const int32_t* prompt_feat_len, const float* const* embedding,
+                             const float* const* z, int n_timesteps, float* const* mel, int mem) {
+  if (!f) return MIA_ERR_MODEL_NOT_LOADED;
+  MIA_CHECK_ARG(f->ctx, n_utt >= 1 && n_utt <= 64 && token && n_token && n_prompt && prompt_feat_len && embedding && z && mel,
+                "flow_inference_batch: bad argument (1..64 utterances)");
+  std::vector<FlowUtt> u((size_t)n_utt);
+  for (int i = 0; i < n_utt; ++i)
+    u[i] = FlowUtt{token[i], n_token[i], prompt_token ? prompt_token[i] : nullptr, n_prompt[i], prompt_feat ? prompt_feat[i] : nullptr,
+                   prompt_feat_len[i], embedding[i], z[i], mel[i], nullptr};
+  return flow_inference_core(f, u.data(), n_utt, n_timesteps, 1, 0, 0, mem);
 }
 
 int mia_flow_inference_streaming(mia_flow* f, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt, const float* prompt_feat,

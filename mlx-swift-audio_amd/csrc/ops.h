@@ -25,6 +25,8 @@ struct AttnF32Args {
   float* out = nullptr; int64_t ldo = 0;
   int B = 1, T = 0, H = 0;
   float scale = 0.125f;
+  const int32_t* seq_len = nullptr;   // device [B], optional: sequence b holds seq_len[b] <= T valid rows (stacked, padded sequences); keys at or
+                                      // beyond it are masked, so a sequence's result equals its own B = 1, T = seq_len[b] call bit for bit
   int chunk = 0;      // > 0: block-causal "streaming" mask, query i sees keys j < (i / chunk + 1) * chunk (subsequentChunkMask,
                       // Codec/S3Gen/Transformer/UpsampleConformerEncoder.swift:124-129); 0 = full attention
 };

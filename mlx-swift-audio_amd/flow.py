@@ -97,6 +97,37 @@ class FlowModule:
         assert nf.value == mel.shape[1]
         return mel
 
+    def inference_batch(self, utterances, n_timesteps: int | None = None) -> list:
+        """Several utterances through one pass of the flow (mia_flow_inference_batch).  `utterances`: sequence of
+        (token, prompt_token, prompt_feat, embedding, z) tuples with the shapes inference() takes; returns their mels in order, each
+        bit-identical to its own inference() call."""
+        lib = self.ctx.lib
+        lib.mia_flow_inference_batch.restype = C.c_int
+        lib.mia_flow_inference_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_int]
+        U = len(utterances)
+        keep, mels = [], []
+        ptr = lambda n: (C.c_void_p * n)()
+        tok, ptok, pfs, embs, zs, outs = ptr(U), ptr(U), ptr(U), ptr(U), ptr(U), ptr(U)
+        n_tok, n_pt, n_pf = np.zeros(U, np.int32), np.zeros(U, np.int32), np.zeros(U, np.int32)
+        for i, (token, prompt_token, prompt_feat, embedding, z) in enumerate(utterances):
+            t = np.ascontiguousarray(token, np.int32)
+            pt = np.ascontiguousarray(prompt_token, np.int32)
+            pf = np.ascontiguousarray(prompt_feat, np.float32).reshape(-1, self.cfg.output_size)
+            e = np.ascontiguousarray(embedding, np.float32).reshape(-1)
+            zz = np.ascontiguousarray(z, np.float32)
+            T = (t.shape[0] + pt.shape[0]) * self.cfg.upsample_stride
+            if zz.shape != (self.cfg.output_size, T) or e.shape[0] != self.cfg.spk_embed_dim:
+                raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, f"flow: utterance {i}: z must be [{self.cfg.output_size}, {T}] and embedding [{self.cfg.spk_embed_dim}]")
+            mel = np.empty((self.cfg.output_size, T - pf.shape[0]), np.float32)
+            keep += [t, pt, pf, e, zz]
+            mels.append(mel)
+            tok[i], ptok[i], pfs[i] = t.ctypes.data, (pt.ctypes.data if pt.size else None), (pf.ctypes.data if pf.size else None)
+            embs[i], zs[i], outs[i] = e.ctypes.data, zz.ctypes.data, mel.ctypes.data
+            n_tok[i], n_pt[i], n_pf[i] = t.shape[0], pt.shape[0], pf.shape[0]
+        self.ctx.check(lib.mia_flow_inference_batch(self.h, U, tok, n_tok.ctypes.data, ptok, n_pt.ctypes.data, pfs, n_pf.ctypes.data, embs, zs,
+                                                    n_timesteps or 0, outs, _lib.MEM_HOST))
+        return mels
+
     def inference(self, token, prompt_token, prompt_feat, embedding, z, n_timesteps: int | None = None) -> np.ndarray:
         """token [n], prompt_token [m] (may be empty), prompt_feat [m1, 80], embedding [spk_embed_dim], z [80, 2 (n + m)] -> mel [80, 2 (n + m) - m1]"""
         t = np.ascontiguousarray(token, np.int32)

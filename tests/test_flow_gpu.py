@@ -125,3 +125,46 @@ def test_attention_chunk_mask_kernel(env):
     a = mod.inference(tok, ptok, pf, emb, z, n_timesteps=2)
     b = mod.inference_streaming(tok, ptok, pf, emb, z, n_timesteps=2, finalize=True, enc_static_chunk=4096, dec_static_chunk=4096)
     np.testing.assert_array_equal(a, b)
+
+
+def _assert_batch_equals_single(mod, utts, n_timesteps):
+    singles = [mod.inference(*u, n_timesteps=n_timesteps) for u in utts]
+    batch = mod.inference_batch(utts, n_timesteps=n_timesteps)
+    assert len(batch) == len(singles)
+    for i, (got, want) in enumerate(zip(batch, singles)):
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), (i, float(np.abs(got - want).max()))       # bit for bit: padding never reaches a valid frame
+    # order and company do not matter either
+    rev = mod.inference_batch(utts[::-1], n_timesteps=n_timesteps)
+    for got, want in zip(rev[::-1], singles):
+        assert np.array_equal(got, want)
+    return singles
+
+
+def test_inference_batch_equals_single_calls(env):
+    """mia_flow_inference_batch: utterances of different lengths, prompt sizes and speakers stacked into one pass give, utterance by
+    utterance, the bits of their own mia_flow_inference call (which the tests above check against the oracle): the look-ahead window,
+    the attention keys and every convolution stay inside the utterance."""
+    from oracle import flow as OF
+    ctx, cfg, w, mod = env
+    utts = [_inputs(cfg, n, m, m1, seed) for (n, m, m1, seed) in ((30, 12, 24, 2), (5, 0, 0, 3), (90, 40, 80, 4), (1, 0, 0, 5), (64, 3, 6, 6))]
+    singles = _assert_batch_equals_single(mod, utts, 3)
+    want, _ = OF.inference(w, cfg, *utts[0], n_timesteps=3)                           # and the batch is the oracle's answer too
+    np.testing.assert_allclose(singles[0], want, atol=1e-3, rtol=1e-3)
+    one = mod.inference_batch(utts[2:3], n_timesteps=3)                               # a batch of one is the single call
+    assert np.array_equal(one[0], singles[2])
+    import mlx_swift_audio_amd as M
+    with pytest.raises(M.MiaError):
+        mod.inference_batch([utts[0]] * 65, n_timesteps=1)
+
+
+def test_inference_batch_production_config():
+    """The same identity at CosyVoice2's production flow configuration (512-wide conformer, 256-channel estimator), 2 Euler steps."""
+    import mlx_swift_audio_amd as M
+    from mlx_swift_audio_amd import flow as HF, synthetic as S
+    ctx = M.Context()
+    cfg = S.FLOW_CONFIGS["flow_cosyvoice2"]
+    mod = HF.FlowModule.load(ctx, cfg, S.flow_weights(cfg))
+    utts = [_inputs(cfg, n, m, m1, seed) for (n, m, m1, seed) in ((120, 50, 100, 11), (37, 50, 100, 12), (200, 0, 0, 13))]
+    _assert_batch_equals_single(mod, utts, 2)
+    mod.close()

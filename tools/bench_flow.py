@@ -35,3 +35,26 @@ for i in range(reps + 1):
 e1.record()
 torch.cuda.synchronize()
 print(f"flow inference: {e0.elapsed_time(e1) / reps:.2f} ms")
+
+# ---- the same utterance U times through mia_flow_inference_batch (device-resident inputs): mel frames per second of the whole batch
+import ctypes as C  # noqa: E402
+
+lib = ctx.lib
+lib.mia_flow_inference_batch.restype = C.c_int
+lib.mia_flow_inference_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_int]
+for U in (2, 4, 8, 16):
+    arr = lambda v: (C.c_void_p * U)(*([v] * U))
+    mels = [torch.empty(80, Tm - 2 * n_prompt, device="cuda") for _ in range(U)]
+    outs = (C.c_void_p * U)(*[m_.data_ptr() for m_ in mels])
+    n1 = np.full(U, n_tok, np.int32); n2 = np.full(U, n_prompt, np.int32); n3 = np.full(U, 2 * n_prompt, np.int32)
+    for i in range(reps + 1):
+        if i == 1:
+            e0.record()
+        ctx.check(lib.mia_flow_inference_batch(fm.h, U, arr(tok.data_ptr()), n1.ctypes.data, arr(ptok.data_ptr()), n2.ctypes.data, arr(pf.data_ptr()),
+                                               n3.ctypes.data, arr(spk.data_ptr()), arr(z.data_ptr()), 0, outs, 1))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    same = all(torch.equal(m_, mel) for m_ in mels)
+    print(f"flow batch {U:2d}: {ms:8.2f} ms = {ms / U:6.2f} ms per utterance, {U * (Tm - 2 * n_prompt) / ms * 1e3:8.0f} mel frames/s "
+          f"({U * (Tm - 2 * n_prompt) / 50.0 / ms * 1e3:6.1f} x real time); every mel equals the single call: {same}")
