@@ -70,6 +70,24 @@ class CosyVoice2Model:
         noise = noise_fn(mel.shape[1] * self.hifigan.up) if noise_fn is not None else None
         return self.mel_to_audio(mel, noise), tokens
 
+    def synthesize_batch(self, texts, cond: CosyVoice2Conditionals, uniforms, z_fn, noise_fn=None, sampling: int = 25, n_timesteps: int = 10,
+                         max_token_text_ratio: float = 20.0, min_token_text_ratio: float = 2.0):
+        """Several sentences of one speaker (the reference loops over them, CosyVoice2Model.swift:155-208): the LM runs sentence by sentence
+        with its own uniform row, then ALL sentences go through one pass of the flow (mia_flow_inference_batch) and the vocoder turns each
+        mel into audio.  Returns [(audio, tokens)] in order; every item equals synthesize() of that sentence with the same draws."""
+        toks = [self.generate_tokens(t, cond.prompt_text, cond.prompt_speech_token, u, sampling, max_token_text_ratio, min_token_text_ratio)
+                for t, u in zip(texts, uniforms)]
+        if any(not t for t in toks):
+            raise ValueError("No tokens generated")
+        utts = [(np.asarray(t, np.int32), cond.prompt_speech_token, cond.prompt_mel, cond.speaker_embedding,
+                 z_fn(2 * (len(t) + len(cond.prompt_speech_token)))) for t in toks]
+        mels = self.flow.inference_batch(utts, n_timesteps)
+        out = []
+        for mel, t in zip(mels, toks):
+            noise = noise_fn(mel.shape[1] * self.hifigan.up) if noise_fn is not None else None
+            out.append((self.mel_to_audio(mel, noise), t))
+        return out
+
     # ---- the other three modes (CosyVoice2Model.swift:253-397): the same three stages, different prompts ----------------------------------
     def _tokens_to_audio(self, tokens, cond, z_fn, noise_fn, n_timesteps):
         if not len(tokens):

@@ -27,6 +27,7 @@ struct SkinnyArgs {
   const int32_t* pos;                    // QKV: per-row (clip) cache position
   int M, N, K, S, act, D, H, n_ctx;
   int out_frag = 0;                      // fragment-order kernels, OUT16: write `out` in activation fragment order (row length N)
+  int w_frag = 0;                        // row-major-activation kernels (the LM step): W is in weight fragment order
 };
 
 int dec_launch_embed_ln(mia_whisper* w, const LNW& ln, hipStream_t s);

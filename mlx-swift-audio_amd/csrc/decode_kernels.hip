@@ -221,11 +221,20 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
   const int Kc = a.K / (a.S * NW);
   const int kbeg = (split * NW + wave) * Kc;
   const int r = lane & 15, c = lane >> 4;
+  // weights: row-major [N][K] (a K-step of a lane = 16 bytes of row r at column 8 c: 16 rows x 64 B per wave instruction), or in
+  // fragment order (decode.h: one contiguous 1 KB per wave instruction); ws = elements between two K-steps of a lane
+  const int ws = a.w_frag ? 512 : 32;
   const uint16_t* wp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    int wn = n0 + 16 * t + r; wn = wn < a.N ? wn : a.N - 1;
-    wp[t] = a.W + (int64_t)wn * a.K + kbeg + 8 * c;
+    if (a.w_frag) {
+      const int tiles = (a.N + 15) >> 4;
+      int tile = (n0 >> 4) + t; tile = tile < tiles ? tile : tiles - 1;
+      wp[t] = a.W + (((int64_t)tile * (a.K >> 5) + (kbeg >> 5)) * 64 + lane) * 8;
+    } else {
+      int wn = n0 + 16 * t + r; wn = wn < a.N ? wn : a.N - 1;
+      wp[t] = a.W + (int64_t)wn * a.K + kbeg + 8 * c;
+    }
   }
   int am0 = m0 + r; am0 = am0 < a.M ? am0 : a.M - 1;
   int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) t.w[u][n] = *reinterpret_cast<const s16x8*>(wp[n] + k + 32 * u);
+      for (int n = 0; n < NT; ++n) t.w[u][n] = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)((k >> 5) + u) * ws);
       t.a0[u] = *reinterpret_cast<const s16x8*>(ap0 + k + 32 * u);
       t.a1[u] = *reinterpret_cast<const s16x8*>(ap1 + k + 32 * u);
     }
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
     const s16x8 fa1 = *reinterpret_cast<const s16x8*>(ap1 + k);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      const s16x8 fw = *reinterpret_cast<const s16x8*>(wp[n] + k);
+      const s16x8 fw = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)(k >> 5) * ws);
       acc[n][0] = T::mfma16(fw, fa0, acc[n][0]);
       acc[n][1] = T::mfma16(fw, fa1, acc[n][1]);
     }
@@ -308,11 +317,18 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
   constexpr int Kc = 32 * NSTEP;
   const int kbeg = (split * NW + wave) * Kc;
   const int r = lane & 15, c = lane >> 4;
+  const int ws = a.w_frag ? 512 : 32;     // weights row-major or in fragment order: see dec_skinny_gemm
   const uint16_t* wp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    int wn = n0 + 16 * t + r; wn = wn < a.N ? wn : a.N - 1;
-    wp[t] = a.W + (int64_t)wn * a.K + kbeg + 8 * c;
+    if (a.w_frag) {
+      const int tiles = (a.N + 15) >> 4;
+      int tile = (n0 >> 4) + t; tile = tile < tiles ? tile : tiles - 1;
+      wp[t] = a.W + (((int64_t)tile * (a.K >> 5) + (kbeg >> 5)) * 64 + lane) * 8;
+    } else {
+      int wn = n0 + 16 * t + r; wn = wn < a.N ? wn : a.N - 1;
+      wp[t] = a.W + (int64_t)wn * a.K + kbeg + 8 * c;
+    }
   }
   int am0 = m0 + r; am0 = am0 < a.M ? am0 : a.M - 1;
   int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
 #pragma unroll
   for (int u = 0; u < NSTEP; ++u) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) fw[u][n] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp[n] + 32 * u));
+    for (int n = 0; n < NT; ++n) fw[u][n] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp[n] + (int64_t)u * ws));
     fa0[u] = *reinterpret_cast<const s16x8*>(ap0 + 32 * u);
     fa1[u] = *reinterpret_cast<const s16x8*>(ap1 + 32 * u);
   }

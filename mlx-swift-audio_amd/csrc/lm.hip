@@ -34,6 +34,10 @@ struct LmLayer {
   void* wo = nullptr;                            // [hidden][Hq*dh]
   void* wgu = nullptr;                           // [2*inter][hidden], rows interleaved gate/up
   void* wdown = nullptr;                         // [hidden][inter]
+  // the same four in MFMA-fragment order (decode.h) for the decode step's skinny GEMMs: one contiguous 1 KB per wave load instead of
+  // 16 rows x 64 B (tools/micro/skinny_probe.hip, Orpheus-3B shapes, one sequence: 48.3 -> 43.7 us per layer); the batched prompt
+  // pass (gemm.hip) keeps reading the row-major copies
+  void* wqkv_f = nullptr; void* wo_f = nullptr; void* wgu_f = nullptr; void* wdown_f = nullptr;
 };
 
 struct mia_lm {
@@ -43,6 +47,7 @@ struct mia_lm {
   std::vector<void*> allocs;
   void* embed = nullptr;        // 16-bit [V][hidden]
   void* lm_head = nullptr;      // 16-bit [V][hidden] (== embed when tied)
+  void* lm_head_f = nullptr;    // lm_head in MFMA-fragment order (decode step)
   Q4W q_head;                   // 4-bit copy of lm_head (mia_lm_attach_q4)
   int q4_scale_dtype = 0;       // MIA_F16 | MIA_BF16: storage type of the checkpoint's scales / biases
   bool q4 = false;              // the step GEMVs stream the packed weights
@@ -967,9 +972,11 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
   const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh, Nqkv = Nq + 2 * Nk;
   const bool f16 = m->dtype == MIA_F16;
   // nb sequences = nb rows of every skinny GEMM: the weights are still read once per step
-  auto skinny = [&](const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int N, int K, int S, int mode, const Q4W* qw = nullptr) {
+  auto skinny = [&](const void* A, int64_t lda, const void* W, const void* Wf, const float* bias, void* out, int64_t ldo, int N, int K, int S, int mode,
+                    const Q4W* qw = nullptr) {
     SkinnyArgs a{(const uint16_t*)A, lda, (const uint16_t*)W, bias, out, ldo, nullptr, nullptr, nullptr, nb, N, K, S, MIA_ACT_NONE, 0, 0, 0};
     if (m->q4 && qw && qw->wfrag) return skinny_gemm_q4_launch(a, qw->wfrag, qw->sbfrag, m->q4_scale_dtype, mode, m->dtype, s);
+    if (Wf) { a.W = (const uint16_t*)Wf; a.w_frag = 1; }      // same K order and partition as the row-major form: identical results
     return skinny_gemm_launch(a, mode, m->dtype, s);
   };
 #define LAUNCH_T(kern, grid, block, lds, ...) do { if (f16) hipLaunchKernelGGL((kern<F16>), grid, block, lds, s, __VA_ARGS__); else hipLaunchKernelGGL((kern<BF16>), grid, block, lds, s, __VA_ARGS__); } while (0)
@@ -979,17 +986,17 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
     const LmLayer& L = m->layers[l];
     uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * layer_stride;
     uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * layer_stride;
-    if (skinny(m->h, D, L.wqkv, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL, &L.q_qkv)) return -1;
+    if (skinny(m->h, D, L.wqkv, L.wqkv_f, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL, &L.q_qkv)) return -1;
     lm_launch_attention(m, true, nb, nullptr, kc, vc, m->att, nullptr, m->qkv_part, m->S_qkv, L.bqkv);      // RoPE + cache row + attention
-    if (skinny(m->att, Nq, L.wo, nullptr, m->partial, 0, D, Nq, m->S_o, SK_PARTIAL, &L.q_o)) return -1;
+    if (skinny(m->att, Nq, L.wo, L.wo_f, nullptr, m->partial, 0, D, Nq, m->S_o, SK_PARTIAL, &L.q_o)) return -1;
     LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_o, L.post_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
-    if (skinny(m->h, D, L.wgu, nullptr, m->act, c.inter, 2 * c.inter, D, 1, SK_SWIGLU, &L.q_gu)) return -1;
-    if (skinny(m->act, c.inter, L.wdown, nullptr, m->partial, 0, D, c.inter, m->S_down, SK_PARTIAL, &L.q_down)) return -1;
+    if (skinny(m->h, D, L.wgu, L.wgu_f, nullptr, m->act, c.inter, 2 * c.inter, D, 1, SK_SWIGLU, &L.q_gu)) return -1;
+    if (skinny(m->act, c.inter, L.wdown, L.wdown_f, nullptr, m->partial, 0, D, c.inter, m->S_down, SK_PARTIAL, &L.q_down)) return -1;
     LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_down, l + 1 < c.n_layers ? m->layers[l + 1].in_norm : m->final_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
   }
 #undef LAUNCH_T
   const int HV = m->head_vocab > 0 ? m->head_vocab : c.vocab;
-  if (skinny(m->h, D, m->lm_head, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32, &m->q_head)) return -1;
+  if (skinny(m->h, D, m->lm_head, m->lm_head_f, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32, &m->q_head)) return -1;
   if (ras) hipLaunchKernelGGL(lm_sample_ras, dim3(nb), dim3(1024), 0, s, m->logits, HV, m->tokens, m->out_tokens, m->uniforms, m->state, *ras, c.max_ctx);
   else if (sampling) { if (lm_sample_launch(s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx, nb)) return -1; }
   else hipLaunchKernelGGL(lm_advance, dim3(nb), dim3(1), 0, s, m->state);
@@ -1228,6 +1235,23 @@ extern "C" mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia
     if (L.to_f32(p + ".mlp.down_proj.weight", t, D, c.inter)) ly.wdown = L.up16(t);
   }
   if (!L.err.empty()) return fail(m, L.err);
+  {  // fragment-order copies for the decode step (one device repack per matrix)
+    bool ok = true;
+    auto frag = [&](const void* src, int N, int K) -> void* {
+      if (!ok || !src || K % 32 != 0) return nullptr;
+      void* dst = nullptr;
+      if (hipMalloc(&dst, (size_t)((N + 15) / 16) * 16 * K * 2) != hipSuccess) { ok = false; return nullptr; }
+      m->allocs.push_back(dst);
+      if (dec_launch_repack_wfrag(src, dst, N, K, ctx->stream) != 0) ok = false;
+      return dst;
+    };
+    for (LmLayer& ly : m->layers) {
+      ly.wqkv_f = frag(ly.wqkv, Nq + 2 * Nk, D); ly.wo_f = frag(ly.wo, D, Nq);
+      ly.wgu_f = frag(ly.wgu, 2 * c.inter, D); ly.wdown_f = frag(ly.wdown, D, c.inter);
+    }
+    m->lm_head_f = frag(m->lm_head, m->head_vocab > 0 ? m->head_vocab : c.vocab, D);
+    if (!ok) return fail(m, "fragment-order repack of the step weights failed");
+  }
   m->S_qkv = pick_split(D, 4); m->S_o = pick_split(Nq, 4); m->S_down = pick_split(c.inter, 8);
   if (lm_alloc_state(m, 1)) return fail(m, "hipMalloc failed (state buffers)");
   if (hipDeviceSynchronize() != hipSuccess) return fail(m, "device error during upload");

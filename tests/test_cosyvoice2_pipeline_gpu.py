@@ -85,6 +85,16 @@ def test_zero_shot_pipeline(ctx):
     got_vc = model.tokens_to_mel(src, cond.prompt_speech_token, cond.prompt_mel, cond.speaker_embedding, draws["z"])
     np.testing.assert_allclose(got_vc, want_vc, atol=2e-3, rtol=2e-3)
     assert va.shape == (2 * src.shape[0] * 480,) and np.abs(va).max() <= 0.99 + 1e-7
+    # ---- several sentences: one pass of the flow for all of them (synthesize_batch), each equal to its own synthesize()
+    texts = [text, [30, 31, 32], [40, 41, 42, 43, 44]]
+    us = [u, rng.random(4000).astype(np.float32), rng.random(4000).astype(np.float32)]
+    z_of = lambda T: np.random.default_rng(1).standard_normal((80, T)).astype(np.float32)          # same draw rule as z_fn
+    n_of = lambda L: np.random.default_rng(2).standard_normal((L, 9)).astype(np.float32)
+    many = model.synthesize_batch(texts, cond, us, z_of, n_of)
+    for (ba, bt), t_, u_ in zip(many, texts, us):
+        sa, st_ = model.synthesize(t_, cond, u_, z_of, n_of)
+        assert bt == st_
+        np.testing.assert_array_equal(ba, sa)
     for h in (flow, hift, s3, spk_enc):
         h.close()
     llm.lm.close()

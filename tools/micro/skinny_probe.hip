@@ -110,8 +110,8 @@ int main() {
   const int M = 32, D = 1280;
   const size_t pool_bytes = (size_t)640 << 20;              // 640 MB of weights, cycled
   uint16_t* pool; CK(hipMalloc(&pool, pool_bytes)); CK(hipMemset(pool, 0x11, pool_bytes));
-  uint16_t* A; CK(hipMalloc(&A, (size_t)M * 4 * D * 2)); CK(hipMemset(A, 0x22, (size_t)M * 4 * D * 2));
-  float* bias; CK(hipMalloc(&bias, 52000 * 4)); CK(hipMemset(bias, 0, 52000 * 4));
+  uint16_t* A; CK(hipMalloc(&A, (size_t)M * 8192 * 2)); CK(hipMemset(A, 0x22, (size_t)M * 8192 * 2));
+  float* bias; CK(hipMalloc(&bias, 70000 * 4)); CK(hipMemset(bias, 0, 70000 * 4));
   void* out; CK(hipMalloc(&out, (size_t)4 * M * 52000 * 4));
   const int reps = 200;
   auto args = [&](int i, int N, int K, int S, int act) {
@@ -191,5 +191,23 @@ int main() {
   RUN("mlp2 fflat NT1 NS10 NW4 S4 grid 80x4 (library)", 1280, 5120, 4, MIA_ACT_NONE, (dec_skinny_fflat<BF16, SK_PARTIAL, 1, 10, 4>), 80, 256);
   RUN("mlp2 fflat NT1 NS5 NW4 S8 grid 80x8 (library)", 1280, 5120, 8, MIA_ACT_NONE, (dec_skinny_fflat<BF16, SK_PARTIAL, 1, 5, 4>), 80, 256);
   RUN("oproj fflat NT1 NS5 NW4 S2 grid 80x2 (library)", 1280, 1280, 2, MIA_ACT_NONE, (dec_skinny_fflat<BF16, SK_PARTIAL, 1, 5, 4>), 80, 256);
+  // ---- Orpheus-3B step shapes (row-major activations; weights row-major vs fragment order), 1 and 32 sequences
+  for (int rows : {1, 32}) {
+    for (int wf = 0; wf < 2; ++wf) {
+      char lab[96];
+#define RUNL(name, N_, K_, S_, KERNEL, gx, threads)                                                                    \
+      snprintf(lab, sizeof lab, "%-28s M=%2d %s", name, rows, wf ? "W fragment order" : "W row-major");                \
+      printf("%-58s %.2f us\n", lab, time_graph(reps, [&](int i) {                                                      \
+        SkinnyArgs a = args(i, N_, K_, S_, MIA_ACT_NONE); a.M = rows; a.w_frag = wf;                                    \
+        hipLaunchKernelGGL(KERNEL, dim3(gx, S_, 1), dim3(threads), 0, g_s, a); }))
+      RUNL("qkv  5120x3072 S4 NW1 KB4", 5120, 3072, 4, (dec_skinny_gemm<BF16, SK_PARTIAL, 1, 4, 1>), 320, 64);
+      RUNL("qkv  5120x3072 S4 NW4 flat6", 5120, 3072, 4, (dec_skinny_flat<BF16, SK_PARTIAL, 1, 6, 4>), 320, 256);
+      RUNL("o    3072x3072 S4 NW4 flat6", 3072, 3072, 4, (dec_skinny_flat<BF16, SK_PARTIAL, 1, 6, 4>), 192, 256);
+      RUNL("gu  16384x3072 S1 NW4 ring", 16384, 3072, 1, (dec_skinny_gemm<BF16, SK_SWIGLU, 1, 2, 4>), 1024, 256);
+      RUNL("down 3072x8192 S8 NW1 KB4", 3072, 8192, 8, (dec_skinny_gemm<BF16, SK_PARTIAL, 1, 4, 1>), 192, 64);
+      RUNL("down 3072x8192 S8 NW4 flat8", 3072, 8192, 8, (dec_skinny_flat<BF16, SK_PARTIAL, 1, 8, 4>), 192, 256);
+      RUNL("head 65536x3072 NT4 NW1 ring", 65536, 3072, 1, (dec_skinny_gemm<BF16, SK_OUTF32, 4, 2, 1>), 1024, 64);
+    }
+  }
   return 0;
 }
