@@ -533,7 +533,10 @@ def main():
                   "bytes_per_launch": dec_bytes_per_step}
         # HBM traffic per launch from the committed PMC passes of this same workload (rocprofv3 cannot run inside the timed process):
         # profiles/r01_pmc_summary.json, made by tools/pmc_summary.py with the guide's gfx950 corrections.  null when absent.
+        # The passes were taken on the headline workload (large-v3-turbo, 32 clips): any other model / batch reports null.
         try:
+            if args.model != "large-v3-turbo" or B != 32:
+                raise KeyError("no PMC passes for this workload")
             pmc_name = next(n for n in ("r02_pmc_summary.json", "r01_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             rl["traffic"] = round(pmc["decode_step"]["hbm_bytes_per_step"] if rl["bound"] == "hbm" else pmc["encoder_gemm"]["hbm_bytes_per_launch"], 0)

@@ -42,6 +42,17 @@ def run(models):
     return time.perf_counter() - t0
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "full":
+    # two (three) full batches of 32 decoding concurrently on their own streams vs one alone: 1.0x = free overlap, 2.0x (3.0x) = serial
+    ms = [make(32), make(32), make(32)]
+    run(ms[:1])
+    t1 = min(run(ms[:1]) for _ in range(2))
+    run(ms[:2])
+    t2 = min(run(ms[:2]) for _ in range(2))
+    run(ms)
+    t3 = min(run(ms) for _ in range(2))
+    print(f"1 x B=32: {t1*1e3:.1f} ms;  2 x B=32 concurrently: {t2*1e3:.1f} ms = {t2/t1:.2f}x;  3 x B=32: {t3*1e3:.1f} ms = {t3/t1:.2f}x")
+    sys.exit(0)
 one = [make(32)]
 run(one)
 t1 = min(run(one) for _ in range(2))
