@@ -280,6 +280,30 @@ def codec_bench(ctx, torch):
     res["flow_cosyvoice2_inference"] = {"mel_frames_per_s": round(n_new / (ms * 1e-3), 0), "ms": round(ms, 3), "new_mel_frames": n_new,
                                         "total_frames": Tm, "euler_steps": fcfg.n_timesteps,
                                         "realtime_factor": round(n_new / 50.0 / (ms * 1e-3), 1)}
+    # the same utterance 8 times through ONE pass (mia_flow_inference_batch: stacked, padded sequences; each mel equals the single call)
+    import ctypes as C
+    U = 8
+    lib = ctx.lib
+    lib.mia_flow_inference_batch.restype = C.c_int
+    lib.mia_flow_inference_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_int]
+    rep = lambda v: (C.c_void_p * U)(*([v] * U))
+    bmels = [torch.empty_like(fmel) for _ in range(U)]
+    outs = (C.c_void_p * U)(*[t.data_ptr() for t in bmels])
+    n1, n2, n3 = np.full(U, n_tok, np.int32), np.full(U, n_prompt, np.int32), np.full(U, 2 * n_prompt, np.int32)
+
+    def run_flow_batch():
+        ctx.check(lib.mia_flow_inference_batch(fm.h, U, rep(tok.data_ptr()), n1.ctypes.data, rep(ptok.data_ptr()), n2.ctypes.data, rep(pfeat.data_ptr()),
+                                               n3.ctypes.data, rep(spk.data_ptr()), rep(zz.data_ptr()), 0, outs, 1))
+
+    run_flow_batch()
+    e0.record()
+    run_flow_batch()
+    e1.record()
+    torch.cuda.synchronize()
+    msb = e0.elapsed_time(e1)
+    res["flow_cosyvoice2_inference_batch8"] = {"mel_frames_per_s": round(U * n_new / (msb * 1e-3), 0), "ms": round(msb, 3), "utterances": U,
+                                               "ms_per_utterance": round(msb / U, 3), "realtime_factor": round(U * n_new / 50.0 / (msb * 1e-3), 1),
+                                               "equals_single_call": bool(all(torch.equal(t, fmel) for t in bmels))}
     fm.close()
     # ---- S3TokenizerV2 (CosyVoice2 prompt path): 10 s of 128-bin mel @ 100 Hz -> 250 speech tokens
     from mlx_swift_audio_amd import s3tok as HS
