@@ -42,7 +42,7 @@ import ctypes as C  # noqa: E402
 lib = ctx.lib
 lib.mia_flow_inference_batch.restype = C.c_int
 lib.mia_flow_inference_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_int]
-for U in (2, 4, 8, 16):
+for U in ((int(sys.argv[2]),) if len(sys.argv) > 2 else (2, 4, 8, 16)):
     arr = lambda v: (C.c_void_p * U)(*([v] * U))
     mels = [torch.empty(80, Tm - 2 * n_prompt, device="cuda") for _ in range(U)]
     outs = (C.c_void_p * U)(*[m_.data_ptr() for m_ in mels])
