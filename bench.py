@@ -23,6 +23,11 @@ import time
 
 import numpy as np
 
+# The replicas' HIP streams must land on distinct hardware queues: with ROCm's default of 4 queues per process two of three replica
+# streams share one and their kernels serialise (three concurrent decoders: 464 ms instead of 377 ms per round, measured).  The knob
+# is read when the runtime initialises, i.e. before the first `import torch`; the launcher's children inherit it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -346,8 +351,11 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--lm", default="", help="also time an LM decode loop and add it as `lm` (e.g. orpheus-3b: ~40 s of extra set-up; off by default)")
     ap.add_argument("--lm-batch", type=int, default=32, help="sentences side by side in the batched part of --lm")
-    ap.add_argument("--replicas", type=int, default=2,
+    ap.add_argument("--replicas", type=int, default=3,
                     help="model replicas on separate HIP streams; passes are dealt round-robin so the encoder of one batch overlaps the decoder of another (1 = strictly serial passes)")
+    ap.add_argument("--phase-log", action="store_true", help="with --schedule phased: log the wall time of every encoder / decoder phase")
+    ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "phased"],
+                    help="how R > 1 replicas share the GPU: pipelined = each replica runs whole passes on its own stream; phased = rounds of R passes, all encoders first, then all decoders concurrently")
     ap.add_argument("--no-config0", action="store_true", help="skip the BASELINE configs[0] leg (tiny.en, one 10 s clip: GPU + CPU at all cores and 1 thread)")
     ap.add_argument("--dp", default="abi", choices=["abi", "torch"], help="token all-gather at N > 1: mia_dp_* (RCCL behind the C ABI, one communicator per replica stream) or torch.distributed")
     args = ap.parse_args()
@@ -425,9 +433,19 @@ def main():
                     self.all_n = torch.zeros(B * world, dtype=torch.int32, device="cuda")
                 self.stream.synchronize()
 
+        def step_encode(self):
+            self.model.encode_windows_device(pcm.data_ptr(), offs)
+
+        def step_decode(self):
+            self.model.decode_greedy_device(self.opts, self.tokens.data_ptr(), self.n_tok.data_ptr(), self.avg.data_ptr(), self.nsp.data_ptr())
+            self._exchange()
+
         def step(self):
             self.model.transcribe_windows_device(pcm.data_ptr(), offs, self.opts, self.tokens.data_ptr(), self.n_tok.data_ptr(), self.avg.data_ptr(),
                                                  self.nsp.data_ptr())
+            self._exchange()
+
+        def _exchange(self):
             if world > 1:              # the path's only exchange, once per pass, on this pass's buffers, behind the decode on the same stream
                 if self.dp_abi:
                     P.dp_gather_tokens(self.ctx, self.tokens.data_ptr(), self.n_tok.data_ptr(), B, self.opts.max_tokens, B * world,
@@ -471,6 +489,32 @@ def main():
 
     def run_passes(k):
         """k passes dealt round-robin over the replicas, one host thread per replica; returns when every stream has drained."""
+        if args.schedule == "phased" and R > 1:
+            # rounds of up to R passes: every replica's log-mel + encoder first (MFMA-bound: they may share the chip freely), then every
+            # replica's decoder concurrently from its own host thread.  Decoders of different batches overlap each other well (three
+            # reach 1.5x the throughput of one, tools/decode_overlap_probe.py); an encoder next to a decoder does not (its 45 us tiles
+            # hold every CU while the decoder's 46 short kernels per step queue behind them).
+            left = k
+            while left > 0:
+                act = reps[:min(R, left)]
+                tp0 = time.perf_counter()
+                for rp in act:
+                    rp.step_encode()
+                for rp in act:
+                    rp.ctx.synchronize()
+                tp1 = time.perf_counter()
+                ths = [threading.Thread(target=rp.step_decode) for rp in act]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                for rp in act:
+                    rp.ctx.synchronize()
+                    rp.stream.synchronize()
+                if args.phase_log:
+                    log(f"[bench] round of {len(act)}: encoders {1e3 * (tp1 - tp0):.1f} ms, decoders {1e3 * (time.perf_counter() - tp1):.1f} ms")
+                left -= len(act)
+            return
         counts = [k // R + (1 if r < k % R else 0) for r in range(R)]
         if R == 1:
             for _ in range(counts[0]):
@@ -596,8 +640,13 @@ def main():
                    "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "generated_tokens_per_clip_mean": float(n_gen.mean()), "decoder_steps_per_pass": steps_d / max(n_d, 1),
                    "realtime_factor": round(value, 1), "replicas": R, "exchange": dp_mode,
-                   "pipeline": (f"{R} model replicas (one weight copy, own activations / KV caches / step graphs) on {R} HIP streams, passes dealt round-robin: the encoder of one batch overlaps the decoder of "
-                                "another; every pass is a complete log-mel + encode + decode of its 32 clips" if R > 1 else "strictly serial passes")},
+                   "schedule": args.schedule if R > 1 else "serial",
+                   "pipeline": ("strictly serial passes" if R == 1 else
+                                f"{R} model replicas (one weight copy, own activations / KV caches / step graphs) on {R} HIP streams, " +
+                                ("rounds of up to R passes: all encoders, then all decoders concurrently (decoders of different batches overlap each other; an encoder beside a decoder does not)"
+                                 if args.schedule == "phased" else
+                                 "passes dealt round-robin: the encoder of one batch overlaps the decoder of another") +
+                                "; every pass is a complete log-mel + encode + decode of its 32 clips")},
         "roofline": roofline, "stages": stage,
     }
     if rank == 0 and not args.no_codec:

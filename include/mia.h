@@ -247,6 +247,11 @@ int mia_whisper_detect_language(mia_whisper* w, int32_t sot, int32_t n_languages
 /* One 30 s window per clip, end to end (log-mel -> encode -> greedy decode), i.e. the body of the reference's
  * transcribe loop for a batch (WhisperSTT.swift:140-145,181-213).  pcm/offs as in mia_logmel_whisper; pcm and the
  * outputs live in `mem`. */
+/* The first half of mia_whisper_transcribe_windows alone: log-mel + encoder (the cross K/V of every decoder layer are primed); follow
+ * with mia_whisper_decode_greedy.  Lets a host that drives several handles run their (MFMA-bound) encoders and their
+ * (latency-bound) decoders in separate phases: decoders of different batches overlap each other well, an encoder next to a decoder does
+ * not. */
+int mia_whisper_encode_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right, int mem);
 int mia_whisper_transcribe_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right,
                                    const mia_decode_opts* opts, int32_t* tokens, int32_t* n_tokens, float* avg_logprob,
                                    float* no_speech_prob, int mem);

@@ -471,13 +471,11 @@ extern "C" int mia_whisper_detect_language(mia_whisper* w, int32_t sot, int32_t 
   return MIA_OK;
 }
 
-extern "C" int mia_whisper_transcribe_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right,
-                                              const mia_decode_opts* opts, int32_t* tokens, int32_t* n_tokens, float* avg_logprob,
-                                              float* no_speech_prob, int mem) {
+extern "C" int mia_whisper_encode_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right, int mem) {
   if (!w) return MIA_ERR_MODEL_NOT_LOADED;
   mia_ctx* ctx = w->ctx;
-  MIA_CHECK_ARG(ctx, pcm && offs && B > 0, "transcribe_windows: null input or B <= 0");
-  MIA_CHECK_ARG(ctx, mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE, "transcribe_windows: bad mem");
+  MIA_CHECK_ARG(ctx, pcm && offs && B > 0, "encode_windows: null input or B <= 0");
+  MIA_CHECK_ARG(ctx, mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE, "encode_windows: bad mem");
   MIA_HIP(ctx, hipSetDevice(ctx->device));
   int rc = whisper_reserve(w, B);
   if (rc != MIA_OK) return rc;
@@ -496,7 +494,13 @@ extern "C" int mia_whisper_transcribe_windows(mia_whisper* w, const float* pcm, 
   rc = mia_logmel_device(ctx, d_pcm, offs, B, d.n_mels, 0, pad_right, rows, w->mel_pad, w->dtype, false,
                          (rows + 2) * d.n_mels, d.n_mels, 1, 1, ws);
   if (rc != MIA_OK) return rc;
-  rc = whisper_encode_from_padded_mel(w, B);
+  return whisper_encode_from_padded_mel(w, B);
+}
+
+extern "C" int mia_whisper_transcribe_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right,
+                                              const mia_decode_opts* opts, int32_t* tokens, int32_t* n_tokens, float* avg_logprob,
+                                              float* no_speech_prob, int mem) {
+  const int rc = mia_whisper_encode_windows(w, pcm, offs, B, pad_right, mem);
   if (rc != MIA_OK) return rc;
   return whisper_decode(w, opts, tokens, n_tokens, avg_logprob, no_speech_prob, mem);
 }

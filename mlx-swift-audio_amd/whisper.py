@@ -56,6 +56,8 @@ def _declare(lib):
     lib.mia_whisper_decode_greedy.argtypes = [vp, C.POINTER(_DecodeOpts), vp, vp, vp, vp, i32]
     lib.mia_whisper_detect_language.restype = i32
     lib.mia_whisper_detect_language.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    lib.mia_whisper_encode_windows.restype = i32
+    lib.mia_whisper_encode_windows.argtypes = [vp, vp, vp, i32, C.c_int64, i32]
     lib.mia_whisper_transcribe_windows.restype = i32
     lib.mia_whisper_transcribe_windows.argtypes = [vp, vp, vp, i32, C.c_int64, C.POINTER(_DecodeOpts), vp, vp, vp, vp, i32]
     lib._whisper_declared = True
@@ -318,6 +320,18 @@ class WhisperModel:
         self.B = len(offs) - 1
         self.ctx.check(self.ctx.lib.mia_whisper_transcribe_windows(self.h, pcm_ptr, offs.ctypes.data, self.B, pad_right, C.byref(co),
                                                                    tokens_ptr, n_ptr, avg_ptr, nsp_ptr, _lib.MEM_DEVICE))
+
+
+    def encode_windows_device(self, pcm_ptr: int, offs: np.ndarray, pad_right: int = _audio.N_SAMPLES) -> None:
+        """The first half of transcribe_windows_device (log-mel + encoder, mia_whisper_encode_windows): only enqueues."""
+        offs = np.ascontiguousarray(offs, np.int64)
+        self.B = len(offs) - 1
+        self.ctx.check(self.ctx.lib.mia_whisper_encode_windows(self.h, pcm_ptr, offs.ctypes.data, self.B, pad_right, _lib.MEM_DEVICE))
+
+    def decode_greedy_device(self, o: DecodingOptions, tokens_ptr: int, n_ptr: int, avg_ptr: int, nsp_ptr: int) -> None:
+        """The second half: greedy decode of the batch encoded last, outputs to device pointers."""
+        co, keep = self._opts(o)
+        self.ctx.check(self.ctx.lib.mia_whisper_decode_greedy(self.h, C.byref(co), tokens_ptr, n_ptr, avg_ptr, nsp_ptr, _lib.MEM_DEVICE))
 
 
 class GreedyDecoder:

@@ -148,6 +148,21 @@ def test_transcribe_windows_end_to_end(ctx):
     for a, b in zip(fused, staged):
         assert a.tokens == b.tokens
         assert a.no_speech_prob == pytest.approx(b.no_speech_prob, rel=1e-5)
+    # the two halves as separate calls on device-resident buffers (mia_whisper_encode_windows + mia_whisper_decode_greedy): same tokens
+    import torch
+    pcm = torch.from_numpy(np.concatenate(clips)).cuda()
+    offs = np.arange(4, dtype=np.int64) * n
+    toks = torch.zeros((3, o.max_tokens), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(3, dtype=torch.int32, device="cuda")
+    avg = torch.zeros(3, dtype=torch.float32, device="cuda")
+    nsp = torch.zeros(3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    model.encode_windows_device(pcm.data_ptr(), offs, pad_right=n)
+    model.decode_greedy_device(o, toks.data_ptr(), cnt.data_ptr(), avg.data_ptr(), nsp.data_ptr())
+    ctx.synchronize()
+    for b, want in enumerate(fused):
+        assert toks[b, :int(cnt[b])].tolist() == want.tokens
+        assert float(nsp[b]) == pytest.approx(want.no_speech_prob, rel=1e-5)
     model.close()
 
 

@@ -44,14 +44,15 @@ def run(models):
 
 if len(sys.argv) > 2 and sys.argv[2] == "full":
     # two (three) full batches of 32 decoding concurrently on their own streams vs one alone: 1.0x = free overlap, 2.0x (3.0x) = serial
-    ms = [make(32), make(32), make(32)]
+    nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    ms = [make(32) for _ in range(nmax)]
     run(ms[:1])
     t1 = min(run(ms[:1]) for _ in range(2))
-    run(ms[:2])
-    t2 = min(run(ms[:2]) for _ in range(2))
-    run(ms)
-    t3 = min(run(ms) for _ in range(2))
-    print(f"1 x B=32: {t1*1e3:.1f} ms;  2 x B=32 concurrently: {t2*1e3:.1f} ms = {t2/t1:.2f}x;  3 x B=32: {t3*1e3:.1f} ms = {t3/t1:.2f}x")
+    print(f"1 x B=32: {t1*1e3:.1f} ms")
+    for n in range(2, nmax + 1):
+        run(ms[:n])
+        tn = min(run(ms[:n]) for _ in range(2))
+        print(f"{n} x B=32 concurrently: {tn*1e3:.1f} ms = {tn/t1:.2f}x of one  ->  {tn/n*1e3:.1f} ms per batch ({n*t1/tn:.2f}x throughput)")
     sys.exit(0)
 one = [make(32)]
 run(one)
