@@ -13,6 +13,8 @@
 //     after the barrier, double buffered), 128-B rows with the 16-B chunk index XOR-swizzled by (row>>1)&7 so
 //     all fragment reads (ds_read_b128) are bank-conflict free;
 //   * V arrives pre-transposed ([B][H][64][Tpad], zero padded) from the QKV GEMM epilogue (gemm.hip QKV_VT).
+#include <type_traits>
+
 #include "mia_device.h"
 #include "ops.h"
 
@@ -92,11 +94,12 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(const uint16_t* _
 
   const int krow = swap23(lq);   // K row fed to MFMA row lq
   const int ntiles = (T_len + KV_TILE - 1) / KV_TILE;
-  load_regs(0);
-  write_lds(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < ntiles; ++kt) {
+  // One K/V tile.  TAIL (the last, partial tile only) masks the keys at or beyond T_len: in the full tiles the masking selects are
+  // not compiled at all (as a runtime `if (tail)` hipcc if-converted them into ~170 of the tile's ~480 instructions, every tile).
+  // The softmax works on the RAW scores: max over s, then p = exp2(fma(s, c, -m c)) with c = scale * log2(e) > 0 -- one fma + one
+  // exp per score instead of mul, sub, exp; the running max is kept raw.
+  auto tile = [&](int kt, int cur, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const int key0 = kt * KV_TILE;
     if (kt + 1 < ntiles) load_regs(key0 + KV_TILE);
     const char* sk = lds + cur * 2 * TILE_BYTES;
@@ -117,22 +120,20 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(const uint16_t* _
     }
     // ---- online softmax (base-2), lane = one query, registers = keys
     float mloc = -INFINITY;
-    const bool tail = key0 + KV_TILE > T_len;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float s = acc_s[kb][r] * scale_log2;
-        if (tail) {
+        if (TAIL) {
           const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key0 + kb * 32 + swap23(i) >= T_len) s = -INFINITY;
+          if (key0 + kb * 32 + swap23(i) >= T_len) acc_s[kb][r] = -INFINITY;
         }
-        acc_s[kb][r] = s;
-        mloc = fmaxf(mloc, s);
+        mloc = fmaxf(mloc, acc_s[kb][r]);
       }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mloc);                   // raw (unscaled) running max; every tile holds >= 1 valid key
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);
+    const float neg_mc = -m_new * scale_log2;
     m_run = m_new;
     float lsum = 0.f;
     s16x8 pf[2][2];
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(const uint16_t* _
       float p[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(acc_s[kb][r] - m_new);
+        p[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[kb][r], scale_log2, neg_mc));
         lsum += p[r];
       }
 #pragma unroll
@@ -173,8 +174,14 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(const uint16_t* _
     }
     if (kt + 1 < ntiles) write_lds(cur ^ 1);
     __syncthreads();
-    cur ^= 1;
-  }
+  };
+  load_regs(0);
+  write_lds(0);
+  __syncthreads();
+  const int nfull = T_len / KV_TILE;
+  int cur = 0;
+  for (int kt = 0; kt < nfull; ++kt) { tile(kt, cur, std::false_type{}); cur ^= 1; }
+  if (nfull < ntiles) tile(nfull, cur, std::true_type{});
 
   // ---- normalise and store: lane owns query q0+lq, d = db*32 + (r&3) + 8*(r>>2) + 4*lh
   l_run += __shfl_xor(l_run, 32, 64);

@@ -56,6 +56,14 @@ template <typename T>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
 }
+// bf16: ONE v_cvt_pk_bf16_f32 (RNE, NaN preserving -- the instruction from_f32 uses, so the bits are the same); written as two
+// scalar conversions + shift + or, hipcc emits four instructions per pair
+template <>
+__device__ __forceinline__ uint32_t pack2<BF16>(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
+}
 
 // ---- wave64 reductions ----------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

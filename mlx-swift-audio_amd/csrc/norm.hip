@@ -2,12 +2,14 @@
 // 16-byte loads, wavefront shuffle reductions, fp32 statistics, 16-bit (or fp32) output for the next GEMM.
 // Replaces MLXNN LayerNorm (eps 1e-5) at ResidualAttentionBlock.swift:65,78,91, AudioEncoder.swift:65,
 // TextDecoder.swift:90, and MLXNN RMSNorm at TTS/Orpheus/BuildingBlocks/TransformerBlock.swift:129-139.
+#include <cstdlib>
 #include "mia_device.h"
 #include "ops.h"
 
 namespace {
 
-template <typename T, bool RMS, bool OUT_F32, int NV>   // NV float4 per lane cached in registers: D <= 256*NV
+// NTX: the rows are streamed once and not needed again soon (the encoder's 246 MB residual stream): non-temporal loads
+template <typename T, bool RMS, bool OUT_F32, int NV, bool NTX = false>   // NV float4 per lane cached in registers: D <= 256*NV
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, void* __restrict__ y, int64_t ldy,
                                                    int M, int D, float eps) {
@@ -22,7 +24,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nv) {
-      v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+      v[i] = NTX ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 4 * c)) : *reinterpret_cast<const f32x4*>(xr + 4 * c);
       if (!RMS) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     } else {
       v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -69,7 +71,11 @@ void launch_nv(const float* x, int64_t ldx, const float* gamma, const float* bet
   dim3 grid((M + 3) / 4), block(256);
 #define L(NV) hipLaunchKernelGGL((norm_kernel<T, RMS, OUT_F32, NV>), grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, D, eps)
   if (D <= 512) L(2);
-  else if (D <= 1280) L(5);
+  else if (D <= 1280) {
+    if ((int64_t)M * D * 4 >= ((int64_t)64 << 20))           // a stream larger than any cache level (measured: 7.24 -> 6.59 ms per pass)
+      hipLaunchKernelGGL((norm_kernel<T, RMS, OUT_F32, 5, true>), grid, block, 0, s, x, ldx, gamma, beta, y, ldy, M, D, eps);
+    else L(5);
+  }
   else if (D <= 2048) L(8);
   else L(16);
 #undef L
