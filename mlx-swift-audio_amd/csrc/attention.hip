@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(const uint16_t* _
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);
     const float neg_mc = -m_new * scale_log2;
     m_run = m_new;
-    // (pairing the scores through v_pk_fma_f32 / v_pk_add_f32 was measured: 231 instead of 256 instructions per tile, 17.0 ms per
-    // pass instead of 16.0 -- the packed fp32 ops are not double rate here)
+    // (pairing the scores through v_pk_fma_f32 / v_pk_add_f32 was measured: 231 instead of 256 instructions per tile, 16.5-16.6 ms
+    // per pass against 16.3-16.4 in alternating runs on one box -- the packed fp32 ops are not double rate here)
     float lsum = 0.f;
     s16x8 pf[2][2];
 #pragma unroll

@@ -468,8 +468,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
   const int n_items = 4 * nk;
   char* const lds_wave = lds + (16 * wave) * 128;
   // item j = 4*t + {0: AX, 1: B0, 2: B1, 3: AY} of K-tile t
-  auto stage_item = [&](int j) {
-    if (j >= n_items) return;
+  // (`guard` = false in the steady part of the K loop, where every staged item exists: the range checks and the run-time choice of
+  // the vmcnt immediate cost 31 scalar branches per pair of K-tiles, in a loop whose 128 MFMAs are otherwise back to back)
+  auto stage_item = [&](int j, bool guard = true) {
+    if (guard && j >= n_items) return;
     const int t = j >> 2, which = j & 3;
     char* dst = lds_wave + (t & 1) * KBUF_BYTES;
     const int kb = t * (BK * 2);
@@ -517,8 +519,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
                                                : T::mfma16(fw[kk][nbase + nt], fa[kk][mt], acc[mbase + mt][nbase + nt]);
       __builtin_amdgcn_s_setprio(0);
     };
-    auto ktile = [&](int kt, auto par_tag) {
+    auto ktile = [&](int kt, auto par_tag, auto steady_tag) {
       constexpr int P = decltype(par_tag)::value;
+      constexpr bool STEADY = decltype(steady_tag)::value;   // items j0 + 6 .. j0 + 9 all exist: no guards, constant waits
       const char* buf = lds + P * KBUF_BYTES;
       const int j0 = 4 * kt;
       // ---------------- phi1
@@ -533,8 +536,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) fa0[kk][t] = *reinterpret_cast<const s16x8*>(buf + OFF_AX + a_rd[kk] + t * 2048);
       }
-      stage_item(j0 + 6);
-      wait_items(min(j0 + 7, n_items) - (j0 + 4));          // AY(kt) landed (read in phi2)
+      stage_item(j0 + 6, !STEADY);
+      if (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else wait_items(min(j0 + 7, n_items) - (j0 + 4));     // AY(kt) landed (read in phi2)
       MIA_BAR();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) fa1[kk][t] = *reinterpret_cast<const s16x8*>(buf + OFF_AY + a_rd[kk] + t * 2048);
       }
-      stage_item(j0 + 7);
+      stage_item(j0 + 7, !STEADY);
       MIA_BAR();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
 #pragma unroll
         for (int t = 2; t < 4; ++t) fa1[kk][t] = *reinterpret_cast<const s16x8*>(buf + OFF_AY + a_rd[kk] + t * 2048);
       }
-      stage_item(j0 + 8);
+      stage_item(j0 + 8, !STEADY);
       MIA_BAR();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -574,8 +578,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
       __builtin_amdgcn_sched_barrier(0);
       MIA_BAR();
       // ---------------- phi4
-      stage_item(j0 + 9);
-      if (kt + 1 < nk) wait_items(min(j0 + 10, n_items) - (j0 + 7));   // AX, B0, B1 of tile kt+1 landed (read in the next phi1)
+      stage_item(j0 + 9, !STEADY);
+      if (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (kt + 1 < nk) wait_items(min(j0 + 10, n_items) - (j0 + 7));   // AX, B0, B1 of tile kt+1 landed (read in the next phi1)
       MIA_BAR();
       __builtin_amdgcn_sched_barrier(0);
       mma16(fa1, 4, 2);
@@ -588,9 +593,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
     wait_items(min(6, n_items) - 3);
     MIA_BAR();
     if (wr == 1) MIA_BAR();          // stagger: the second wave group runs one barrier behind the first
-    for (int kt = 0; kt < nk; kt += 2) {
-      ktile(kt, std::integral_constant<int, 0>{});
-      if (kt + 1 < nk) ktile(kt + 1, std::integral_constant<int, 1>{});
+    // steady pairs: both tiles stage items up to 4 (kt + 1) + 9 < n_items, i.e. kt + 1 <= nk - 3
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 2) {      // (same-process A/B against the all-guarded loop: +0.7 ... +5.5 % on the four encoder shapes)
+      ktile(kt, std::integral_constant<int, 0>{}, std::true_type{});
+      ktile(kt + 1, std::integral_constant<int, 1>{}, std::true_type{});
+    }
+    for (; kt < nk; kt += 2) {
+      ktile(kt, std::integral_constant<int, 0>{}, std::false_type{});
+      if (kt + 1 < nk) ktile(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
     }
     if (wr == 0) MIA_BAR();
   };
