@@ -639,18 +639,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
                         (EPI == MIA_EPI_STD || n0 + BN2 <= 2 * g.H * 64);
     if (rows16) {
       char* reg = lds + wave * 16384;
+      // (the activation switch is taken ONCE per tile: tested per value it compiled into a branch around every one of the 128 GELUs)
+      auto stage16 = [&](auto gelu_tag) {
+        constexpr bool GELU = decltype(gelu_tag)::value;
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        const int row = mt * 16 + e_m;
+        for (int mt = 0; mt < 8; ++mt) {
+          const int row = mt * 16 + e_m;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          float v[4];
+          for (int nt = 0; nt < 4; ++nt) {
+            float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(acc[mt][nt][j] + bias4[nt][j], g.act);
-          const int c16 = nt * 2 + (lane >> 5), half = (lane >> 4) & 1;
-          *reinterpret_cast<u32x2*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4) + half * 8) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+            for (int j = 0; j < 4; ++j) { v[j] = acc[mt][nt][j] + bias4[nt][j]; if (GELU) v[j] = gelu_erf(v[j]); }
+            const int c16 = nt * 2 + (lane >> 5), half = (lane >> 4) & 1;
+            *reinterpret_cast<u32x2*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4) + half * 8) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+          }
         }
-      }
+      };
+      if (g.act == MIA_ACT_GELU) stage16(std::true_type{}); else stage16(std::false_type{});
       uint16_t* cb = reinterpret_cast<uint16_t*>(g.C) + (EPI == MIA_EPI_STD ? (int64_t)bz * g.strideC : 0);
       const int c16 = lane & 7;
       const int n = n0 + wc * 64 + c16 * 8;
@@ -676,6 +681,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
       const float* rb = g.R ? g.R + (int64_t)bz * g.strideR : nullptr;
       const int c16 = lane & 15;
       const int n = n0 + wc * 64 + c16 * 4;
+      const bool gelu32 = g.act == MIA_ACT_GELU;
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
@@ -685,7 +691,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
           for (int nt = 0; nt < 4; ++nt) {
             f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = apply_act<T>(acc[mh * 4 + mt][nt][j] + bias4[nt][j], g.act);
+            for (int j = 0; j < 4; ++j) v[j] = acc[mh * 4 + mt][nt][j] + bias4[nt][j];
+            if (gelu32) {          // uniform; the encoder's fp32-output GEMMs (out-proj, fc2) carry no activation
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            }
             const int wc16 = nt * 4 + (lane >> 4);
             *reinterpret_cast<f32x4*>(reg + row * 256 + ((wc16 ^ (row & 15)) << 4)) = v;
           }

@@ -82,7 +82,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // erff, which cost ~45 % of the MLP1 GEMM when run 245 M times per layer in its epilogue.
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  // v_rcp_f32 (1 ulp): __frcp_rn is the correctly rounded quotient, which hipcc expands into the ten-instruction IEEE division sequence
+  // (div_scale x2, rcp, four fma, div_fmas, div_fixup) -- per GELU value, in the fc1 epilogue -- for a result whose last bit the
+  // 1.5e-7 approximation error swamps anyway
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
