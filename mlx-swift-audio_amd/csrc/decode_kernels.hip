@@ -388,8 +388,33 @@ int dec_launch_repack_wfrag(const void* src, void* dst, int N, int K, hipStream_
 }
 
 // lane holds C[m = m0 + mt*16 + r][n = n0 + 16t + 4c + j], j = 0..3: one vector store per (t, mt)
+// The epilogue's small dependent loads (the lane's 4 bias values per tile, the cache position of its two rows) are issued by
+// skinny_prefetch at the START of the kernel, next to the operand loads: fetched in the epilogue they added an L2 round trip to every
+// biased GEMM of the chain, after the reduction barrier where nothing hides it.
+template <int NT>
+struct SkinnyPre { float bs[NT][4]; int pos[2]; };
+
+template <int MODE, int NT>
+__device__ __forceinline__ SkinnyPre<NT> skinny_prefetch(const SkinnyArgs& a, int n0, int m0, int lane) {
+  SkinnyPre<NT> p;
+  const int r = lane & 15, c = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + 4 * c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.bs[t][j] = (MODE != SK_PARTIAL && a.bias && n + j < a.N) ? a.bias[n + j] : 0.f;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = m0 + mt * 16 + r;
+    p.pos[mt] = (MODE == SK_QKV && m < a.M) ? a.pos[m] : 0;
+  }
+  return p;
+}
+
 template <typename T, int MODE, int NT>
-__device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane) {
+__device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], const SkinnyPre<NT>& pre, int n0, int m0, int split,
+                                                  int lane) {
   static_assert(MODE != SK_SWIGLU, "the fragment-order kernels serve the Whisper step");
   const int r = lane & 15, c = lane >> 4;
 #pragma unroll
@@ -397,11 +422,7 @@ __device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32
     const int n = n0 + 16 * t + 4 * c;
     if (n >= a.N) continue;
     const bool full = n + 3 < a.N;
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE != SK_PARTIAL && a.bias) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (n + j < a.N) bs[j] = a.bias[n + j];
-    }
+    const float (&bs)[4] = pre.bs[t];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int m = m0 + mt * 16 + r;
@@ -436,7 +457,7 @@ __device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32
       if (n < a.D) { *reinterpret_cast<u32x2*>(o16 + (int64_t)m * a.ldo + n) = pk; continue; }
       const int hd = (n - a.D) % a.D, h = hd >> 6, d = hd & 63;
       uint16_t* cache = n < 2 * a.D ? a.cache_k : a.cache_v;
-      *reinterpret_cast<u32x2*>(cache + (((int64_t)m * a.H + h) * a.n_ctx + a.pos[m]) * 64 + d) = pk;
+      *reinterpret_cast<u32x2*>(cache + (((int64_t)m * a.H + h) * a.n_ctx + pre.pos[mt]) * 64 + d) = pk;
     }
   }
 }
@@ -457,6 +478,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fflat(SkinnyArgs a) {
     wp[t] = a.W + (((int64_t)tile * ksteps + ks0) * 64 + lane) * 8;
   }
   const uint16_t* ap = a.A + ((((int64_t)z * ksteps + ks0) * 2) * 64 + lane) * 8;
+  const SkinnyPre<NT> pre = skinny_prefetch<MODE, NT>(a, blockIdx.x * (16 * NT), z * 32, lane);
   s16x8 fw[NSTEP][NT], fa0[NSTEP], fa1[NSTEP];
 #pragma unroll
   for (int u = 0; u < NSTEP; ++u) {
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fflat(SkinnyArgs a) {
       acc[n][1] = T::mfma16(fw[u][n], fa1[u], acc[n][1]);
     }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_epilogue_v<T, MODE, NT>(a, acc, blockIdx.x * (16 * NT), z * 32, split, lane);
+  skinny_epilogue_v<T, MODE, NT>(a, acc, pre, blockIdx.x * (16 * NT), z * 32, split, lane);
 }
 
 // any K slice per wave (K == 32 * S * NW * steps): a ring of four register batches of KB K-steps, three in flight
@@ -495,6 +517,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
     wp[t] = a.W + (((int64_t)tile * ksteps + ks0) * 64 + lane) * 8;
   }
   const uint16_t* ap = a.A + ((((int64_t)z * ksteps + ks0) * 2) * 64 + lane) * 8;
+  const SkinnyPre<NT> pre = skinny_prefetch<MODE, NT>(a, blockIdx.x * (16 * NT), z * 32, lane);
   f32x4 acc[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -550,7 +573,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
     }
   }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_epilogue_v<T, MODE, NT>(a, acc, blockIdx.x * (16 * NT), z * 32, split, lane);
+  skinny_epilogue_v<T, MODE, NT>(a, acc, pre, blockIdx.x * (16 * NT), z * 32, split, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -683,10 +706,12 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
     if (NTL) return __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(p));
     return *reinterpret_cast<const s16x8*>(p);
   };
+  // (rows are clamped to the cache's capacity, not to nk: rows in [nk, cap_keys) exist and hold finite values -- zeros or older
+  // positions -- and every use of them is masked; so the first trip's loads do not wait for the position load that nk depends on)
   auto load_trip = [&](s16x8 (&dst)[U], const uint16_t* base, int k0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      int key = k0 + 8 * u + g; key = key < nk ? key : nk - 1;
+      int key = k0 + 8 * u + g; key = key < cap_keys ? key : cap_keys - 1;
       dst[u] = ld(base + (int64_t)key * 64 + c * 8);
     }
   };
@@ -695,7 +720,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   {
     int k0 = wave * (8 * U);
     s16x8 kv[U], kn[U];
-    if (k0 < nk) load_trip(kv, kb, k0);
+    if (k0 < cap_keys) load_trip(kv, kb, k0);
     for (; k0 < nk; k0 += TRIP) {
       const bool more = k0 + TRIP < nk;
       if (more) load_trip(kn, kb, k0 + TRIP);
@@ -718,7 +743,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   }
   // the first V trip does not depend on the probabilities: its loads fly during the softmax
   s16x8 vv[U], vn[U];
-  if (wave * (8 * U) < nk) load_trip(vv, vb, wave * (8 * U));
+  if (wave * (8 * U) < cap_keys) load_trip(vv, vb, wave * (8 * U));
   __syncthreads();
   // word-timestamp alignment (WhisperTiming.swift:605-640): keep the pre-softmax scores of the alignment heads, row = decoder position
   if (qk_out && head_slot[h] >= 0) {
@@ -1047,10 +1072,16 @@ __global__ __launch_bounds__(256) void dec_head_partial(HeadBufs hb, DecodeParam
   __shared__ float sha[4][2];
   __shared__ int shai[4][2];
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const HeadRule r = head_rule(hb, p, b);
-  if (!r.active) return;
   const int V = p.V, tsb = p.timestamp_begin;
   const float* lg = hb.logits + (int64_t)b * V;
+  // the slice's logits do not depend on the clip's rule state: their loads go out first, so the rule's chain of small dependent
+  // loads (position -> generated count -> last tokens) runs in their shadow instead of ahead of them
+  const int base = k * (256 * HEAD_NPT2);
+  float x[HEAD_NPT2];
+#pragma unroll
+  for (int u = 0; u < HEAD_NPT2; ++u) { const int i = base + tid + 256 * u; x[u] = i < V ? lg[i] : -INFINITY; }
+  const HeadRule r = head_rule(hb, p, b);
+  if (!r.active) return;
   const int nw = (V + 31) / 32;
   const uint32_t* bits = hb.suppress + (r.num_gen == 0 ? nw : 0);
   auto maskedA = [&](int i) -> bool {
@@ -1065,10 +1096,6 @@ __global__ __launch_bounds__(256) void dec_head_partial(HeadBufs hb, DecodeParam
     }
     return false;
   };
-  const int base = k * (256 * HEAD_NPT2);
-  float x[HEAD_NPT2];
-#pragma unroll
-  for (int u = 0; u < HEAD_NPT2; ++u) { const int i = base + tid + 256 * u; x[u] = i < V ? lg[i] : -INFINITY; }
   float mx_text = -INFINITY, mx_ts = -INFINITY;
   ArgMax bA{-INFINITY, 0x7fffffff}, bB{-INFINITY, 0x7fffffff};
   unsigned okA = 0u;
