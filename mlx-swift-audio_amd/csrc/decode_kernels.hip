@@ -706,12 +706,10 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
     if (NTL) return __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(p));
     return *reinterpret_cast<const s16x8*>(p);
   };
-  // (rows are clamped to the cache's capacity, not to nk: rows in [nk, cap_keys) exist and hold finite values -- zeros or older
-  // positions -- and every use of them is masked; so the first trip's loads do not wait for the position load that nk depends on)
   auto load_trip = [&](s16x8 (&dst)[U], const uint16_t* base, int k0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      int key = k0 + 8 * u + g; key = key < cap_keys ? key : cap_keys - 1;
+      int key = k0 + 8 * u + g; key = key < nk ? key : nk - 1;
       dst[u] = ld(base + (int64_t)key * 64 + c * 8);
     }
   };
@@ -720,7 +718,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   {
     int k0 = wave * (8 * U);
     s16x8 kv[U], kn[U];
-    if (k0 < cap_keys) load_trip(kv, kb, k0);
+    if (k0 < nk) load_trip(kv, kb, k0);
     for (; k0 < nk; k0 += TRIP) {
       const bool more = k0 + TRIP < nk;
       if (more) load_trip(kn, kb, k0 + TRIP);
@@ -743,7 +741,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   }
   // the first V trip does not depend on the probabilities: its loads fly during the softmax
   s16x8 vv[U], vn[U];
-  if (wave * (8 * U) < cap_keys) load_trip(vv, vb, wave * (8 * U));
+  if (wave * (8 * U) < nk) load_trip(vv, vb, wave * (8 * U));
   __syncthreads();
   // word-timestamp alignment (WhisperTiming.swift:605-640): keep the pre-softmax scores of the alignment heads, row = decoder position
   if (qk_out && head_slot[h] >= 0) {
