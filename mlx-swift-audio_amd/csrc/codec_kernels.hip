@@ -22,9 +22,19 @@ __device__ __forceinline__ float snake_f(float x, float a, float ra) {
   const float s = __sinf(a * x);
   return x + ra * (s * s);
 }
-// full-precision variant used where the argument can be large
+// sin with an explicit two-constant Cody-Waite reduction in front of v_sin_f32 (which takes revolutions): k = rint(x / 2 pi),
+// r = (x - k C1) - k C2 with C1 + C2 = 2 pi split so that k C1 is exact for |k| < 2^12 -- absolute error ~2e-7 for |x| < 2.5e4,
+// six instructions instead of libm sinf's ~40 (its Payne-Hanek path is compiled in for every call).  The snake prologue runs it on
+// every staged activation of every codec GEMM tile.
+__device__ __forceinline__ float sin_cw(float x) {
+  const float k = rintf(x * 0.15915494309189535f);
+  float r = fmaf(-k, 6.28125f, x);                       // C1: 2 pi to 12 significant bits
+  r = fmaf(-k, 1.9353071795864769e-03f, r);              // C2 = 2 pi - C1
+  return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
+}
+// variant used where the argument can be large (snake_f's bare v_sin_f32 loses accuracy with |a x|)
 __device__ __forceinline__ float snake_p(float x, float a, float ra) {
-  const float s = sinf(a * x);
+  const float s = sin_cw(a * x);
   return x + ra * (s * s);
 }
 
