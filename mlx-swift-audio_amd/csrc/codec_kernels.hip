@@ -71,30 +71,56 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   const int s_row = tid >> 3, s_col = (tid & 7) * 4;
   float4 ra[KC][2 * WM], rb[KC][2 * WN];
   uint32_t amask = 0, bmask = 0;            // bit (ch * 8 + i): element is inside the tensor
-  int kcur = 0;                             // K offset of the stage held in ra / rb
+  // Per-thread row bases, once per tile.  The stage loop then only adds a wave-uniform tap offset and clamps the OFFSET (a masked
+  // element's address just has to stay inside the tensor): no integer division (k0 / Cin) and no 64-bit multiply per row and chunk --
+  // they were ~100 quarter-rate integer multiplies per K stage, in a loop whose wave also does the MFMAs.
+  int xr0[2 * WM], xo0[2 * WM];
+  int64_t wb[2 * WN];
+  uint32_t mok = 0, nok = 0;
+  const int ldx_i = (int)g.ldx, xo_max = (g.T_in - 1) * ldx_i;       // host-checked: every row offset fits 31 bits
+#pragma unroll
+  for (int i = 0; i < 2 * WM; ++i) {
+    const int m = m0 + s_row + 32 * i;
+    xr0[i] = m * g.x_row_mul - g.pad;
+    xo0[i] = xr0[i] * ldx_i;
+    mok |= (m < g.M ? 1u : 0u) << i;
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * WN; ++i) {
+    const int n = n0 + s_row + 32 * i;
+    wb[i] = (int64_t)(n < g.N ? n : g.N - 1) * ldw + s_col;
+    nok |= (n < g.N ? 1u : 0u) << i;
+  }
+  int cc_s[KC];                             // per chunk of the staged stage: channel offset inside its tap
+  int tap_b = 0, cb = 0;                    // the stage's first chunk starts at k = tap_b * Cin + cb (stages are visited in order)
   auto load_tiles = [&](int kbase) {
-    kcur = kbase; amask = 0; bmask = 0;
+    if (kbase > 0) {                        // advance by one stage (wave-uniform scalar work)
+      cb += GBK;
+      while (cb >= g.Cin) { cb -= g.Cin; ++tap_b; }
+    }
+    amask = 0; bmask = 0;
 #pragma unroll
     for (int ch = 0; ch < KC; ++ch) {
-      int k0 = kbase + 32 * ch;
-      const bool kin = k0 < Ktot;
-      k0 = kin ? k0 : Ktot - 32;
-      const int tap = k0 / g.Cin, c0 = k0 - tap * g.Cin + s_col;
+      int tap = tap_b, cc = cb + 32 * ch;
+#pragma unroll
+      for (int w2 = 0; w2 < KC; ++w2) if (cc >= g.Cin) { cc -= g.Cin; ++tap; }       // Cin >= 32: at most KC - 1 wraps inside a stage
+      const bool kin = tap < g.taps;        // == (kbase + 32 ch < Ktot)
+      if (!kin) { tap = g.taps - 1; cc = g.Cin - 32; }
+      cc_s[ch] = cc;
+      const int k0 = tap * g.Cin + cc;
+      const int tapd = tap * g.dil, tapo = tapd * ldx_i;
 #pragma unroll
       for (int i = 0; i < 2 * WM; ++i) {
-        const int m = m0 + s_row + 32 * i;
-        const int xr = m * g.x_row_mul + tap * g.dil - g.pad;    // host checks that M * x_row_mul fits 31 bits
-        const bool ok = kin && m < g.M && xr >= 0 && xr < T_valid;
-        const int xc = xr < 0 ? 0 : (xr < g.T_in ? xr : g.T_in - 1);
-        ra[ch][i] = *reinterpret_cast<const float4*>(X + (int64_t)xc * g.ldx + c0);
+        const int xr = xr0[i] + tapd;
+        const bool ok = kin && ((mok >> i) & 1u) && xr >= 0 && xr < T_valid;
+        const int xo = min(max(xo0[i] + tapo, 0), xo_max);
+        ra[ch][i] = *reinterpret_cast<const float4*>(X + xo + cc + s_col);
         amask |= (ok ? 1u : 0u) << (ch * 8 + i);
       }
 #pragma unroll
       for (int i = 0; i < 2 * WN; ++i) {
-        const int n = n0 + s_row + 32 * i;
-        const int nc = n < g.N ? n : g.N - 1;
-        rb[ch][i] = *reinterpret_cast<const float4*>(W + (int64_t)nc * ldw + k0 + s_col);
-        bmask |= ((kin && n < g.N) ? 1u : 0u) << (ch * 8 + i);
+        rb[ch][i] = *reinterpret_cast<const float4*>(W + wb[i] + k0);
+        bmask |= ((kin && ((nok >> i) & 1u)) ? 1u : 0u) << (ch * 8 + i);
       }
     }
   };
@@ -103,8 +129,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
     for (int ch = 0; ch < KC; ++ch) {
       float al[4] = {0.f, 0.f, 0.f, 0.f}, ral[4] = {0.f, 0.f, 0.f, 0.f};
       if (g.alpha) {
-        int k0 = kcur + 32 * ch; k0 = k0 < Ktot ? k0 : Ktot - 32;
-        const int c0 = k0 % g.Cin + s_col;
+        const int c0 = cc_s[ch] + s_col;                  // channel offset of this chunk inside its tap (set by load_tiles)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { al[j] = g.alpha[c0 + j]; ral[j] = g.ralpha ? g.ralpha[c0 + j] : 1.0f / (al[j] + 1e-9f); }
       }
@@ -391,6 +416,7 @@ const char* codec_conv_gemm_check(const ConvGemmArgs& g) {
   if (g.ldx % 4 || ((uintptr_t)g.X & 15) || ((uintptr_t)g.W & 15)) return "conv_gemm: X rows / W must be 16-byte aligned";
   if (g.noise && !g.R) return "conv_gemm: noise modulation needs the residual input";
   if ((int64_t)g.M * g.x_row_mul + (int64_t)g.taps * g.dil > 0x7fffffffLL) return "conv_gemm: row index exceeds 31 bits";
+  if (((int64_t)g.M * g.x_row_mul + (int64_t)g.taps * g.dil + g.pad + g.T_in) * g.ldx > 0x7fffffffLL) return "conv_gemm: row offset exceeds 31 bits";
   return nullptr;
 }
 
