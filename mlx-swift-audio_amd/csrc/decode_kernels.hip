@@ -212,6 +212,117 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const f32x4
   }
 }
 
+// The epilogue's small dependent loads (the lane's 4 bias values per tile, the cache position of its two rows) are issued by
+// skinny_prefetch at the START of the kernel, next to the operand loads: fetched in the epilogue they added an L2 round trip to every
+// biased GEMM of the chain, after the reduction barrier where nothing hides it.
+template <int NT>
+struct SkinnyPre { float bs[NT][4]; int pos[2]; };
+
+template <int MODE, int NT>
+__device__ __forceinline__ SkinnyPre<NT> skinny_prefetch(const SkinnyArgs& a, int n0, int m0, int lane) {
+  SkinnyPre<NT> p;
+  const int r = lane & 15, c = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + 4 * c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p.bs[t][j] = (MODE != SK_PARTIAL && a.bias && n + j < a.N) ? a.bias[n + j] : 0.f;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = m0 + mt * 16 + r;
+    p.pos[mt] = (MODE == SK_QKV && m < a.M) ? a.pos[m] : 0;
+  }
+  return p;
+}
+
+template <typename T, int MODE, int NT>
+__device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], const SkinnyPre<NT>& pre, int n0, int m0, int split,
+                                                  int lane) {
+  static_assert(MODE != SK_SWIGLU, "SK_SWIGLU is stored by skinny_store");
+  const int r = lane & 15, c = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + 4 * c;
+    if (n >= a.N) continue;
+    const bool full = n + 3 < a.N;
+    const float (&bs)[4] = pre.bs[t];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = m0 + mt * 16 + r;
+      if (m >= a.M) continue;
+      f32x4 v = acc[t][mt];
+      if (MODE == SK_PARTIAL) {
+        float* dst = reinterpret_cast<float*>(a.out) + ((int64_t)split * a.M + m) * a.N + n;
+        if (full && (a.N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+        else { for (int j = 0; j < 4; ++j) if (n + j < a.N) dst[j] = v[j]; }
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] += bs[j]; if (a.act == MIA_ACT_GELU) v[j] = gelu_erf(v[j]); }
+      if (MODE == SK_OUTF32) {
+        float* dst = reinterpret_cast<float*>(a.out) + (int64_t)m * a.ldo + n;
+        if (full && (a.ldo & 1) == 0) {
+          *reinterpret_cast<f32x2*>(dst) = (f32x2){v[0], v[1]};
+          *reinterpret_cast<f32x2*>(dst + 2) = (f32x2){v[2], v[3]};
+        } else { for (int j = 0; j < 4; ++j) if (n + j < a.N) dst[j] = v[j]; }
+        continue;
+      }
+      const u32x2 pk = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+      uint16_t* o16 = reinterpret_cast<uint16_t*>(a.out);
+      if (MODE == SK_OUT16) {
+        if (a.out_frag) { *reinterpret_cast<u32x2*>(o16 + afrag_index(m, n, a.N)) = pk; continue; }   // host-checked: N % 16 == 0
+        uint16_t* dst = o16 + (int64_t)m * a.ldo + n;
+        if (full && (a.ldo & 3) == 0) *reinterpret_cast<u32x2*>(dst) = pk;
+        else { for (int j = 0; j < 4; ++j) if (n + j < a.N) dst[j] = T::from_f32(v[j]); }
+        continue;
+      }
+      // SK_QKV (host-checked: D % 64 == 0, N == 3 D): [0,D) -> q row-major, [D,2D) -> self K cache, [2D,3D) -> self V cache at pos[m]
+      if (n < a.D) { *reinterpret_cast<u32x2*>(o16 + (int64_t)m * a.ldo + n) = pk; continue; }
+      const int hd = (n - a.D) % a.D, h = hd >> 6, d = hd & 63;
+      uint16_t* cache = n < 2 * a.D ? a.cache_k : a.cache_v;
+      *reinterpret_cast<u32x2*>(cache + (((int64_t)m * a.H + h) * a.n_ctx + pre.pos[mt]) * 64 + d) = pk;
+    }
+  }
+}
+
+// Row-major-activation kernels (the LM step): the same vector stores.  SK_SWIGLU: a lane's 4 consecutive columns are (gate, up, gate, up)
+// -> two outputs, one 4-byte store; SK_QKV keeps the scalar form (the Whisper step, its only user, runs the fragment-order kernels).
+template <typename T, int MODE, int NT>
+__device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane) {
+  if constexpr (MODE == SK_QKV) {
+    skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
+  } else if constexpr (MODE == SK_SWIGLU) {
+    const int r = lane & 15, c = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + 16 * t + 4 * c;
+      if (n >= a.N) continue;
+      float bs[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n + j < a.N) bs[j] = a.bias[n + j];
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + mt * 16 + r;
+        if (m >= a.M) continue;
+        float o[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float v = acc[t][mt][2 * q] + bs[2 * q], u = acc[t][mt][2 * q + 1] + bs[2 * q + 1];
+          o[q] = (v / (1.0f + __expf(-v))) * u;
+        }
+        uint16_t* dst = reinterpret_cast<uint16_t*>(a.out) + (int64_t)m * a.ldo + (n >> 1);
+        if (n + 3 < a.N && (a.ldo & 1) == 0) *reinterpret_cast<uint32_t*>(dst) = pack2<T>(o[0], o[1]);
+        else { dst[0] = T::from_f32(o[0]); if (n + 2 < a.N) dst[1] = T::from_f32(o[1]); }
+      }
+    }
+  } else {
+    skinny_epilogue_v<T, MODE, NT>(a, acc, skinny_prefetch<MODE, NT>(a, n0, m0, lane), n0, m0, split, lane);
+  }
+}
+
 template <typename T, int MODE, int NT, int KB, int NW>
 __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -300,7 +411,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
     }
   }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
+  skinny_store<T, MODE, NT>(a, acc, n0, m0, split, lane);
 }
 
 // The same GEMM for a SHORT K-slice per wave (exactly NSTEP K-steps of 32, host-checked: K == S * NW * 32 * NSTEP): every operand
@@ -354,7 +465,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
       acc[n][1] = T::mfma16(fw[u][n], fa1[u], acc[n][1]);
     }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
+  skinny_store<T, MODE, NT>(a, acc, n0, m0, split, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -388,80 +499,6 @@ int dec_launch_repack_wfrag(const void* src, void* dst, int N, int K, hipStream_
 }
 
 // lane holds C[m = m0 + mt*16 + r][n = n0 + 16t + 4c + j], j = 0..3: one vector store per (t, mt)
-// The epilogue's small dependent loads (the lane's 4 bias values per tile, the cache position of its two rows) are issued by
-// skinny_prefetch at the START of the kernel, next to the operand loads: fetched in the epilogue they added an L2 round trip to every
-// biased GEMM of the chain, after the reduction barrier where nothing hides it.
-template <int NT>
-struct SkinnyPre { float bs[NT][4]; int pos[2]; };
-
-template <int MODE, int NT>
-__device__ __forceinline__ SkinnyPre<NT> skinny_prefetch(const SkinnyArgs& a, int n0, int m0, int lane) {
-  SkinnyPre<NT> p;
-  const int r = lane & 15, c = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int n = n0 + 16 * t + 4 * c;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p.bs[t][j] = (MODE != SK_PARTIAL && a.bias && n + j < a.N) ? a.bias[n + j] : 0.f;
-  }
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int m = m0 + mt * 16 + r;
-    p.pos[mt] = (MODE == SK_QKV && m < a.M) ? a.pos[m] : 0;
-  }
-  return p;
-}
-
-template <typename T, int MODE, int NT>
-__device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], const SkinnyPre<NT>& pre, int n0, int m0, int split,
-                                                  int lane) {
-  static_assert(MODE != SK_SWIGLU, "the fragment-order kernels serve the Whisper step");
-  const int r = lane & 15, c = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int n = n0 + 16 * t + 4 * c;
-    if (n >= a.N) continue;
-    const bool full = n + 3 < a.N;
-    const float (&bs)[4] = pre.bs[t];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int m = m0 + mt * 16 + r;
-      if (m >= a.M) continue;
-      f32x4 v = acc[t][mt];
-      if (MODE == SK_PARTIAL) {
-        float* dst = reinterpret_cast<float*>(a.out) + ((int64_t)split * a.M + m) * a.N + n;
-        if (full && (a.N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
-        else { for (int j = 0; j < 4; ++j) if (n + j < a.N) dst[j] = v[j]; }
-        continue;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] += bs[j]; if (a.act == MIA_ACT_GELU) v[j] = gelu_erf(v[j]); }
-      if (MODE == SK_OUTF32) {
-        float* dst = reinterpret_cast<float*>(a.out) + (int64_t)m * a.ldo + n;
-        if (full && (a.ldo & 1) == 0) {
-          *reinterpret_cast<f32x2*>(dst) = (f32x2){v[0], v[1]};
-          *reinterpret_cast<f32x2*>(dst + 2) = (f32x2){v[2], v[3]};
-        } else { for (int j = 0; j < 4; ++j) if (n + j < a.N) dst[j] = v[j]; }
-        continue;
-      }
-      const u32x2 pk = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-      uint16_t* o16 = reinterpret_cast<uint16_t*>(a.out);
-      if (MODE == SK_OUT16) {
-        if (a.out_frag) { *reinterpret_cast<u32x2*>(o16 + afrag_index(m, n, a.N)) = pk; continue; }   // host-checked: N % 16 == 0
-        uint16_t* dst = o16 + (int64_t)m * a.ldo + n;
-        if (full && (a.ldo & 3) == 0) *reinterpret_cast<u32x2*>(dst) = pk;
-        else { for (int j = 0; j < 4; ++j) if (n + j < a.N) dst[j] = T::from_f32(v[j]); }
-        continue;
-      }
-      // SK_QKV (host-checked: D % 64 == 0, N == 3 D): [0,D) -> q row-major, [D,2D) -> self K cache, [2D,3D) -> self V cache at pos[m]
-      if (n < a.D) { *reinterpret_cast<u32x2*>(o16 + (int64_t)m * a.ldo + n) = pk; continue; }
-      const int hd = (n - a.D) % a.D, h = hd >> 6, d = hd & 63;
-      uint16_t* cache = n < 2 * a.D ? a.cache_k : a.cache_v;
-      *reinterpret_cast<u32x2*>(cache + (((int64_t)m * a.H + h) * a.n_ctx + pre.pos[mt]) * 64 + d) = pk;
-    }
-  }
-}
-
 // short K slice per wave (NSTEP K-steps, host-checked K == 32 * S * NW * NSTEP): every load ahead of the first MFMA.  Weights are
 // loaded non-temporal (measured against default-policy loads, hoping the 184 MB of layer weights would stay in the 256 MB MALL from
 // step to step: they do not, 0.424 vs 0.418 ms per step)
@@ -668,7 +705,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_q4(SkinnyArgs a, Q4Frag q
     mma_blk(k2);
   }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
+  skinny_store<T, MODE, NT>(a, acc, n0, m0, split, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
