@@ -377,11 +377,27 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
   };
   constexpr int KSTEP = 32 * KB;
   const int nb = Kc / KSTEP;
-  int k = 0;
+  // The K-steps left over after the whole batches (< KB of them).  On a SHORT slice (at most 3 batches: the ring's fourth register
+  // batch is idle) their loads are issued up front into that batch -- fetched after the main loop, one step at a time, they were up
+  // to KB - 1 extra dependent memory round trips at the end of every launch (Qwen2-0.5B: K / S = 224 = one batch of 4 steps + 3 such
+  // steps, in each of its 72 projection launches per token: 0.876 -> 0.80 ms per token).  Long slices keep the trailing loop: a fifth
+  // register batch would cost the 64-thread form its occupancy (measured on Orpheus-3B: 1.96 -> 2.15 ms per token).
+  const int ktail = nb * KSTEP, rem = (Kc - ktail) >> 5;
+  const bool early_tail = nb <= 3 && rem > 0;
+  Batch b0, b1, b2, b3;
+  if (early_tail) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+      if (u < rem) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b3.w[u][n] = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)((ktail >> 5) + u) * ws);
+        b3.a0[u] = *reinterpret_cast<const s16x8*>(ap0 + ktail + 32 * u);
+        b3.a1[u] = *reinterpret_cast<const s16x8*>(ap1 + ktail + 32 * u);
+      }
+  }
   if (nb > 0) {
     // ring of four register batches (static names: runtime-indexed vector arrays would go to scratch): three batches of
     // loads are always in flight behind the batch being multiplied
-    Batch b0, b1, b2, b3;
     load_batch(b0, 0);
     if (nb > 1) load_batch(b1, KSTEP);
     if (nb > 2) load_batch(b2, 2 * KSTEP);
@@ -398,16 +414,27 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
       if (i + 6 < nb) load_batch(b2, (i + 6) * KSTEP);
       mma_batch(b3);
     }
-    k = nb * KSTEP;
   }
-  for (; k < Kc; k += 32) {
-    const s16x8 fa0 = *reinterpret_cast<const s16x8*>(ap0 + k);
-    const s16x8 fa1 = *reinterpret_cast<const s16x8*>(ap1 + k);
+  if (early_tail) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const s16x8 fw = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)(k >> 5) * ws);
-      acc[n][0] = T::mfma16(fw, fa0, acc[n][0]);
-      acc[n][1] = T::mfma16(fw, fa1, acc[n][1]);
+    for (int u = 0; u < KB; ++u)
+      if (u < rem) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[n][0] = T::mfma16(b3.w[u][n], b3.a0[u], acc[n][0]);
+          acc[n][1] = T::mfma16(b3.w[u][n], b3.a1[u], acc[n][1]);
+        }
+      }
+  } else {
+    for (int k = ktail; k < Kc; k += 32) {
+      const s16x8 fa0 = *reinterpret_cast<const s16x8*>(ap0 + k);
+      const s16x8 fa1 = *reinterpret_cast<const s16x8*>(ap1 + k);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const s16x8 fw = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)(k >> 5) * ws);
+        acc[n][0] = T::mfma16(fw, fa0, acc[n][0]);
+        acc[n][1] = T::mfma16(fw, fa1, acc[n][1]);
+      }
     }
   }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
