@@ -252,6 +252,46 @@ def sample_from_distribution(probs: np.ndarray, r: float) -> int:
     return min(i, probs.shape[0] - 1)
 
 
+def rule_masks(tokens: list[int], initial_count: int, st: SpecialTokens, o: DecodingOptions, V: int):
+    """The two additive masks (0 / -inf) GreedyDecoder builds before the timestamp-probability heuristic: the suppress-token mask
+    (WhisperDecoding.swift:190-206: the caller's list, plus blanks and EOT before the first generated token) and the timestamp-rule mask
+    (:214-290: <|notimestamps|>, timestamps in pairs, monotonic timestamps with the port's strict `> timestampBegin` filter and its
+    `+1 iff penultimateWasTimestamp`, first token a timestamp no later than max_initial_timestamp).  tests/test_oracle_whisper_rules.py
+    compares them with `transformers`' WhisperTimeStampLogitsProcessor / SuppressTokens processors."""
+    NEG = -float("inf")
+    idx = torch.arange(V)
+    num_generated = len(tokens) - initial_count
+    sup = list(o.suppress_ids)                                           # :190-198 (caller passes the full list)
+    if num_generated == 0:
+        sup = sup + list(o.blank_ids) + [st.eot]                         # :201-206
+    base = torch.zeros(V)
+    for t in sup:
+        if t < V:
+            base[t] = NEG
+    ts_mask = torch.zeros(V)
+    tsb = st.timestamp_begin
+    if o.timestamps:
+        ts_mask[st.no_timestamps] = NEG
+        last_was_ts = num_generated >= 1 and tokens[-1] >= tsb
+        penult_was_ts = num_generated < 2 or tokens[-2] >= tsb
+        if last_was_ts:
+            if penult_was_ts:
+                ts_mask[idx >= tsb] = NEG
+            else:
+                ts_mask[idx < st.eot] = NEG
+        gen = tokens[len(tokens) - num_generated:] if num_generated else []
+        ts_vals = [t for t in gen if t > tsb]                            # strict > (:254-256)
+        if ts_vals:
+            lt = ts_vals[-1] + (1 if penult_was_ts else 0)
+            ts_mask[(idx >= tsb) & (idx < lt)] = NEG
+        if num_generated == 0:
+            ts_mask[idx < tsb] = NEG
+            last_allowed = tsb + o.max_initial_timestamp_index
+            if last_allowed < V:
+                ts_mask[idx > last_allowed] = NEG
+    return base, ts_mask
+
+
 def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: DecodingOptions, uniforms=None) -> DecodingResult:
     """GreedyDecoder.decode (WhisperDecoding.swift:96-389) for ONE clip (xa [1, n_audio_ctx, D]).  temperature 0 = argmax;
     temperature > 0 samples with `uniforms[k]` standing in for the k-th Float.random(in: 0..<1) of the reference."""
@@ -277,34 +317,8 @@ def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: 
             no_speech_prob = float(probs[st.no_speech])
         last = logits[0, -1].clone()
         num_generated = len(tokens) - initial_count
-        sup = list(o.suppress_ids)                                       # :190-198 (caller passes the full list)
-        if it == 0:
-            sup = sup + list(o.blank_ids) + [st.eot]                     # :201-206
-        base = torch.zeros(V)
-        for t in sup:
-            if t < V:
-                base[t] = NEG
-        ts_mask = torch.zeros(V)
+        base, ts_mask = rule_masks(tokens, initial_count, st, o, V)
         tsb = st.timestamp_begin
-        if o.timestamps:
-            ts_mask[st.no_timestamps] = NEG
-            last_was_ts = num_generated >= 1 and tokens[-1] >= tsb
-            penult_was_ts = num_generated < 2 or tokens[-2] >= tsb
-            if last_was_ts:
-                if penult_was_ts:
-                    ts_mask[idx >= tsb] = NEG
-                else:
-                    ts_mask[idx < st.eot] = NEG
-            gen = tokens[len(tokens) - num_generated:] if num_generated else []
-            ts_vals = [t for t in gen if t > tsb]                        # strict > (:254-256)
-            if ts_vals:
-                lt = ts_vals[-1] + (1 if penult_was_ts else 0)
-                ts_mask[(idx >= tsb) & (idx < lt)] = NEG
-            if num_generated == 0:
-                ts_mask[idx < tsb] = NEG
-                last_allowed = tsb + o.max_initial_timestamp_index
-                if last_allowed < V:
-                    ts_mask[idx > last_allowed] = NEG
         force_ts = False
         if o.timestamps and num_generated > 0:                           # :299-322 on RAW logits
             lp = last - torch.logsumexp(last, dim=-1, keepdim=True)
