@@ -791,9 +791,9 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
         float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) dot += qf[j] * T::to_f32((uint16_t)kv[u][j]);
-        dot += __shfl_xor(dot, 1, 64);
-        dot += __shfl_xor(dot, 2, 64);
-        dot += __shfl_xor(dot, 4, 64);
+        dot += dpp_xor1(dot);            // 8-lane all-reduce on DPP (the lanes of a key): no LDS-crossbar round trips in the K loop
+        dot += dpp_xor2(dot);
+        dot += dpp_half_mirror(dot);
         const int key = k0 + 8 * u + g;
         if (c == 0 && key < nk) sc[key] = dot * scale;
       }
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    acc[j] += __shfl_xor(acc[j], 8, 64);
+    acc[j] += dpp_xor8(acc[j]);
     acc[j] += __shfl_xor(acc[j], 16, 64);
     acc[j] += __shfl_xor(acc[j], 32, 64);
   }
@@ -888,12 +888,15 @@ __device__ __forceinline__ ArgMax amax(ArgMax a, ArgMax b) {   // larger value w
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
 __device__ __forceinline__ ArgMax wave_amax(ArgMax a) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    ArgMax b{__shfl_xor(a.v, o, 64), __shfl_xor(a.i, o, 64)};
-    a = amax(a, b);
-  }
-  return a;
+  // rows of 16 on DPP, then the four row winners as scalars (amax is associative and commutative: any order gives the same pair)
+#define AMAX_STEP(CTRL) { const ArgMax b{dpp_f32<CTRL>(a.v), dpp_i32<CTRL>(a.i)}; a = amax(a, b); }
+  AMAX_STEP(0xB1) AMAX_STEP(0x4E) AMAX_STEP(0x141) AMAX_STEP(0x140)
+#undef AMAX_STEP
+  ArgMax r = ArgMax{lane_f32(a.v, 0), __builtin_amdgcn_readlane(a.i, 0)};
+  r = amax(r, ArgMax{lane_f32(a.v, 16), __builtin_amdgcn_readlane(a.i, 16)});
+  r = amax(r, ArgMax{lane_f32(a.v, 32), __builtin_amdgcn_readlane(a.i, 32)});
+  r = amax(r, ArgMax{lane_f32(a.v, 48), __builtin_amdgcn_readlane(a.i, 48)});
+  return r;
 }
 
 // One workgroup per clip.  The clip's logits are read once into registers; pass 1 = every max / argmax, pass 2 = every

@@ -66,15 +66,42 @@ __device__ __forceinline__ uint32_t pack2<BF16>(float lo, float hi) {
 }
 
 // ---- wave64 reductions ----------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// All-reduce over the 64 lanes; every lane gets the result.  The 16-lane rows are reduced with DPP row operations (full-rate VALU
+// modifiers: quad swap, quad pair swap, half-row mirror, row mirror), the four row totals are then read as scalars and combined in
+// a fixed order.  `__shfl_xor` compiles to ds_bpermute_b32 -- a round trip through the LDS crossbar per butterfly step, six dependent
+// ones per reduction -- which showed in the decode chain's row kernels (two to eight reductions each inside ~3 us of work).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+__device__ __forceinline__ float lane_f32(float v, int lane) {     // v_readlane_b32 on the bits (the builtin's operand is an int)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f32<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);    // row_half_mirror
+  v += dpp_f32<0x140>(v);    // row_mirror: every lane of a row holds the row's sum
+  const float r0 = lane_f32(v, 0), r1 = lane_f32(v, 16), r2 = lane_f32(v, 32), r3 = lane_f32(v, 48);
+  return (r0 + r1) + (r2 + r3);
+}
+// partial butterflies on DPP for the in-row steps of hand-written reductions: xor 1 / xor 2 (quad permutes), the half-row mirror
+// (lane i <-> 7 - i of its group of 8: after the two quad steps it completes an 8-lane all-reduce exactly like xor 4) and the
+// 8-lane rotation inside a 16-lane row (== xor 8)
+__device__ __forceinline__ float dpp_xor1(float v) { return dpp_f32<0xB1>(v); }
+__device__ __forceinline__ float dpp_xor2(float v) { return dpp_f32<0x4E>(v); }
+__device__ __forceinline__ float dpp_half_mirror(float v) { return dpp_f32<0x141>(v); }
+__device__ __forceinline__ float dpp_xor8(float v) { return dpp_f32<0x128>(v); }     // row_ror:8
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  const float r0 = lane_f32(v, 0), r1 = lane_f32(v, 16), r2 = lane_f32(v, 32), r3 = lane_f32(v, 48);
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // exact (erf) GELU, MLXNN GELU() default.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far
