@@ -93,6 +93,8 @@ __global__ __launch_bounds__(256) void dec_embed_ln(const int32_t* __restrict__ 
 }
 
 // x[b] += bias + sum_s partial[s][b];  h[b] = LN(x[b])        (residual add + next LayerNorm, fixed-order split-K sum)
+// (A one-wave-per-row form -- no LDS hop, no barrier, the statistics as plain DPP wave reductions -- was measured: 1.6 us SLOWER per
+// launch; a single wave issuing the row's 30-40 loads takes longer than four waves with two barriers.)
 template <typename T>
 __global__ __launch_bounds__(256) void dec_reduce_ln(const float* __restrict__ partial, int S, int B, const float* __restrict__ bias,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
