@@ -629,8 +629,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
   const int e_m = lane & 15, e_n = (lane >> 4) * 4;
   const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && (g.R == nullptr || (g.ldr & 3) == 0);
   f32x4 bias4[4];
+  // the wave's 64 columns all exist and the pointer is 16-byte aligned (one wave-uniform test): four back-to-back 16-byte loads, one
+  // L2 round trip.  As guarded scalar loads hipcc emitted a branch per element with `s_waitcnt vmcnt(0)` between the groups -- several
+  // dependent round trips at the head of every tile's epilogue.
+  if (g.bias && (((uintptr_t)g.bias) & 15) == 0 && n0 + wc * 64 + 64 <= g.N) {
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) bias4[nt] = load_bias4(g, n0 + wc * 64 + nt * 16 + e_n);
+    for (int nt = 0; nt < 4; ++nt) bias4[nt] = *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 64 + nt * 16 + e_n);
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias4[nt] = load_bias4(g, n0 + wc * 64 + nt * 16 + e_n);
+  }
   if constexpr (!OUT_F32 && (EPI == MIA_EPI_STD || EPI == MIA_EPI_QKV_VT)) {
     // 16-bit row-major output: the direct store is 32 x 8 B per lane in 32-B row pieces and is store-ISSUE-bound (a third of a
     // K = 1280 tile's time).  Stage the wave's 128 x 64 sub-tile in its own 16 KB of the (now idle) LDS -- 128-B rows, 16-B chunk
