@@ -692,6 +692,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
       const bool gelu32 = g.act == MIA_ACT_GELU;
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh) {
+        // the half's 16 residual vectors first: unconditional loads (row / column clamped into the tensor, unused lanes discard them),
+        // so that they are all in flight while the accumulators are staged -- fetched inside the store loop, under its bounds test,
+        // each one was a dependent memory round trip (load, s_waitcnt vmcnt(0), add, store, 16 times per half)
+        f32x4 rv[16];
+        if (rb) {
+          const int nc = n < g.N ? n : 0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            int m = m0 + wr * 128 + mh * 64 + 4 * i + (lane >> 4);
+            m = m < g.M ? m : g.M - 1;
+            rv[i] = *reinterpret_cast<const f32x4*>(rb + (int64_t)m * g.ldr + nc);
+          }
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int row = mt * 16 + e_m;
@@ -713,14 +726,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
           const int row = 4 * i + (lane >> 4);
           f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 256 + ((c16 ^ (row & 15)) << 4));
           const int m = m0 + wr * 128 + mh * 64 + row;
-          if (m < g.M && n < g.N) {
-            if (rb) {
-              const f32x4 rv = *reinterpret_cast<const f32x4*>(rb + (int64_t)m * g.ldr + n);
+          if (rb) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] += rv[j];
-            }
-            *reinterpret_cast<f32x4*>(cb + (int64_t)m * g.ldc + n) = v;
+            for (int j = 0; j < 4; ++j) v[j] += rv[i][j];
           }
+          if (m < g.M && n < g.N) *reinterpret_cast<f32x4*>(cb + (int64_t)m * g.ldc + n) = v;
         }
       }
       return;
