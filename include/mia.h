@@ -223,6 +223,18 @@ mia_whisper* mia_whisper_clone(mia_whisper* src, mia_ctx* ctx);
  * (default), 4: 256^2 8-phase).  Results are identical up to fp32 summation order; anything else is MIA_ERR_INVALID_ARGUMENT. */
 int mia_whisper_set_gemm_variant(mia_whisper* w, int variant);
 
+/* Test hooks of the decode step (never used by the product path).
+ *   mia_whisper_set_debug: bit 0 = launch every step's kernels directly instead of replaying the captured hipGraph, bit 1 = the
+ *     one-workgroup decode head at temperature 0 too (normally the split argmax head).  Results must not change.
+ *   mia_whisper_trace_logits: from now on every decode step ALSO copies the raw fp32 logits (before the logit rules) of the listed
+ *     batch rows into a trace [n_clips][n_text_ctx][n_vocab], filed under the position of the token the step consumed -- the copy is a
+ *     node of the same captured step graph, so the trace is what the graph computed.  n_clips = 0 switches it off (<= 8 rows).
+ *   mia_whisper_read_logit_trace: rows [first_pos, first_pos + n_pos) of trace slot `slot` -> out (host float32 [n_pos][n_vocab]).
+ * Used by tests/ to compare the step path's logits with the oracle's teacher-forced logits at every step (TextDecoder.swift:53-96). */
+int mia_whisper_set_debug(mia_whisper* w, int flags);
+int mia_whisper_trace_logits(mia_whisper* w, const int32_t* clips, int n_clips);
+int mia_whisper_read_logit_trace(mia_whisper* w, int slot, int first_pos, int n_pos, float* out);
+
 /* Replaces model.encode(mel) (WhisperDecoding.swift:98 -> AudioEncoder.swift:43-68) for a batch of 30 s windows and
  * primes the decoder's cross-attention K/V (MultiHeadAttention.swift:49-59).
  *   mel: [B][2*n_audio_ctx][n_mels] in the model's compute dtype. */
@@ -349,6 +361,9 @@ mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia_tensor_vie
  * prompt pass keeps the 16-bit copy.  mia_lm_use_q4 toggles the step between the two (0 = 16-bit). */
 int mia_lm_attach_q4(mia_lm* lm, const mia_tensor_view* tensors, int n_tensors, int group_size);
 int mia_lm_use_q4(mia_lm* lm, int on);
+/* Test hook: bit 0 = launch every step's kernels directly (no hipGraph), bit 1 = feed prompts token by token (no batched prompt
+ * pass).  Results agree up to fp32 summation order. */
+int mia_lm_set_debug(mia_lm* lm, int flags);
 void mia_lm_free(mia_lm* lm);
 int mia_lm_reset(mia_lm* lm);
 /* model(ids, cache) then logits[0,-1] (OrpheusTTS.swift:245-251,289): appends n ids to the KV cache, returns the fp32

@@ -44,5 +44,7 @@ int skinny_gemm_q4_launch(const SkinnyArgs& a, const uint32_t* wfrag, const uint
 int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const void* vc, void* out, int fixed_keys, int cap_keys,
                          hipStream_t s, float* qk_out = nullptr, const int32_t* head_slot = nullptr, int n_slots = 0, int qk_ctx = 0);
 bool dec_head_is_split(const DecodeParams& p);
+// test hook: logits of the traced clips -> w->trace[slot][pos[clip]][0:V]
+int dec_launch_trace(mia_whisper* w, hipStream_t s);
 int dec_launch_head(mia_whisper* w, int32_t* last_ts, const DecodeParams& p, hipStream_t s);
 int dec_launch_finalize(mia_whisper* w, int32_t* out_n, const DecodeParams& p, hipStream_t s);

@@ -1498,8 +1498,25 @@ int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const vo
 // true when the greedy head runs as partial + final kernels; the final kernel then also embeds the next position, so the step graph
 // carries no dec_embed_ln of its own (the caller launches it once before the first step)
 bool dec_head_is_split(const DecodeParams& p) {
-  static const bool one_block = getenv("MIA_HEAD_SINGLE") != nullptr;
-  return p.greedy && !one_block && p.V <= 256 * HEAD_NPT2 * HEAD_SPLIT;
+  return p.greedy && !p.head_single && p.V <= 256 * HEAD_NPT2 * HEAD_SPLIT;
+}
+
+// test hook (mia_whisper_trace_logits): the raw logits the head is about to read, for the traced clips, filed under the position of
+// the token this step consumed.  Runs inside the captured step graph, so what is traced is what the graph computed.
+__global__ __launch_bounds__(256) void dec_trace_logits(const float* __restrict__ logits, const int32_t* __restrict__ pos, const int32_t* __restrict__ clips,
+                                                        float* __restrict__ trace, int V, int n_ctx) {
+  const int slot = blockIdx.y, b = clips[slot];
+  const int p = pos[b];
+  if (p < 0 || p >= n_ctx) return;
+  const float* src = logits + (int64_t)b * V;
+  float* dst = trace + ((int64_t)slot * n_ctx + p) * V;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < V; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+int dec_launch_trace(mia_whisper* w, hipStream_t s) {
+  if (!w->trace || w->trace_n <= 0) return -1;
+  hipLaunchKernelGGL(dec_trace_logits, dim3(32, w->trace_n), dim3(256), 0, s, w->logits, w->clip.pos, w->trace_clips, w->trace, w->dims.n_vocab, w->dims.n_text_ctx);
+  return 0;
 }
 
 int dec_launch_head(mia_whisper* w, int32_t* last_ts, const DecodeParams& p, hipStream_t s) {

@@ -71,6 +71,7 @@ struct mia_lm {
   LmState* state = nullptr;
   hipGraphExec_t graph = nullptr;       // one decode step (forward / top-p sampler / RAS sampler), re-captured when its sampler arguments change
   int graph_mode = -1;                  // 0 forward, 1 top-p, 2 RAS
+  int debug_flags = 0;                  // test hook (mia_lm_set_debug): bit 0 = no hipGraph, bit 1 = no batched prompt pass
   mia_lm_sampler graph_sampler{};
   RasParams graph_ras{};
   int S_qkv = 1, S_o = 1, S_down = 1;
@@ -1015,7 +1016,7 @@ constexpr int PF_ROWS = 512;
 constexpr int PF_MIN_ROWS = 8;     // below this the step graph is as fast
 
 bool lm_prefill_supported(const mia_lm* m) {
-  static const bool off = getenv("MIA_LM_NO_PREFILL") != nullptr;
+  const bool off = (m->debug_flags & 2) != 0;      // test hook (mia_lm_set_debug)
   const mia_lm_config& c = m->cfg;
   return !off && c.hidden % 64 == 0 && (c.n_heads * c.head_dim) % 64 == 0 && c.inter % 64 == 0;
 }
@@ -1097,8 +1098,7 @@ int lm_prefill(mia_lm* m, int pos0, int P, int seq = 0) {
 
 int lm_graph(mia_lm* m, int mode, const mia_lm_sampler& sp, const RasParams* ras = nullptr, int nb = 1) {
   mia_ctx* ctx = m->ctx;
-  static const bool no_graph = getenv("MIA_NO_GRAPH") != nullptr;
-  if (no_graph) return 1;
+  if (m->debug_flags & 1) return 1;                  // test hook (mia_lm_set_debug): launch every step directly
   mia_lm_sampler key{}; RasParams rkey{};
   if (mode == 1) key = sp;
   if (mode == 2) rkey = *ras;
@@ -1357,6 +1357,13 @@ extern "C" int mia_lm_attach_q4(mia_lm* m, const mia_tensor_view* tensors, int n
 }
 
 // switch the step between the packed (1) and the 16-bit (0) weights of a handle that has both (A/B timing, parity tests)
+extern "C" int mia_lm_set_debug(mia_lm* m, int flags) {
+  if (!m) return MIA_ERR_MODEL_NOT_LOADED;
+  MIA_CHECK_ARG(m->ctx, flags >= 0 && flags <= 3, "lm_set_debug: flags must be 0..3 (got %d)", flags);
+  m->debug_flags = flags;
+  return MIA_OK;
+}
+
 extern "C" int mia_lm_use_q4(mia_lm* m, int on) {
   if (!m) return MIA_ERR_MODEL_NOT_LOADED;
   MIA_CHECK_ARG(m->ctx, !on || m->q4_scale_dtype != 0, "lm_use_q4: no packed weights attached");

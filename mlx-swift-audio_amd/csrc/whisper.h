@@ -56,6 +56,8 @@ struct DecodeParams {  // immutable per graph (kernel argument, by value)
   int eot, no_speech, no_timestamps, timestamp_begin;
   int timestamps, max_tokens, max_initial_ts, max_new_tokens;
   int greedy;                   // every clip decodes at temperature 0: the argmax head may be split over several workgroups
+  int trace;                    // test hook (mia_whisper_trace_logits): the step also copies the traced clips' logits out
+  int head_single;              // test hook (mia_whisper_set_debug bit 1): one-workgroup head even at temperature 0
 };
 
 struct mia_whisper {
@@ -122,6 +124,13 @@ struct mia_whisper {
   hipGraphExec_t step_graph_n = nullptr;   // DEC_GRAPH_STEPS consecutive steps in one graph (one replay gap instead of DEC_GRAPH_STEPS)
   DecodeParams graph_params{};
   bool graph_valid = false;
+
+  // ---- test hooks (never set by the product path)
+  int debug_flags = 0;                // mia_whisper_set_debug: bit 0 = launch every step directly (no hipGraph), bit 1 = one-workgroup head
+  float* trace = nullptr;             // mia_whisper_trace_logits: fp32 [trace_n][n_text_ctx][V], row p = the logits computed at position p
+  int32_t* trace_clips = nullptr;     // device int32 [trace_n]: batch rows traced
+  int trace_n = 0;
+  std::vector<int32_t> trace_clip_ids;
 };
 
 // whisper_encode.hip

@@ -97,6 +97,7 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p, const AlignHook* hook = 
     LinearW e; e.w = w->tok_emb; e.wf = w->tok_emb_f; e.N = p.V; e.K = D;
     if (skinny(dh, D, e, false, w->logits, p.V, 1, MIA_ACT_NONE, SK_OUTF32)) return -1;
   }
+  if (p.trace && !hook && dec_launch_trace(w, s)) return -1;
   if (hook) {
     hipLaunchKernelGGL(align_token_prob, dim3(B), dim3(256), 0, s, w->logits, w->tokens, w->clip.pos, hook->n_tok, hook->probs, p.V, C, hook->eot);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -130,6 +131,9 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
   p.eot = o->eot; p.no_speech = o->no_speech; p.no_timestamps = o->no_timestamps; p.timestamp_begin = o->timestamp_begin;
   p.timestamps = o->timestamps ? 1 : 0; p.max_tokens = o->max_tokens;
   p.max_initial_ts = o->max_initial_timestamp_index; p.max_new_tokens = o->max_new_tokens;
+  p.trace = w->trace ? 1 : 0; p.head_single = (w->debug_flags & 2) ? 1 : 0;
+  if (w->trace)
+    for (int i = 0; i < w->trace_n; ++i) MIA_CHECK_ARG(ctx, w->trace_clip_ids[i] < w->cur_B, "decode: traced clip %d is not in this batch of %d", w->trace_clip_ids[i], w->cur_B);
 
   // ---- per-clip forced prefixes, probe positions, temperatures, activity (host -> device, small)
   std::vector<int32_t> n_init(B), sot_idx(B), fin(B, 0);
@@ -187,7 +191,7 @@ int whisper_decode(mia_whisper* w, const mia_decode_opts* o, int32_t* tokens, in
   // ---- hipGraphs per (batch, rule set): every kernel reads per-clip positions from device memory, so the same graph replays for
   // every step.  Two are kept: one step, and DEC_GRAPH_STEPS consecutive steps (between two replays the queue idles for ~8.5 us,
   // between two nodes of one graph it does not: 447 steps cost 56 + 7 replay gaps instead of 447).
-  static const bool no_graph = getenv("MIA_NO_GRAPH") != nullptr;
+  const bool no_graph = (w->debug_flags & 1) != 0;
   constexpr int DEC_GRAPH_STEPS = 8;
   if (!no_graph && (!w->graph_valid || memcmp(&w->graph_params, &p, sizeof(p)) != 0)) {
     if (w->step_graph) { (void)hipGraphExecDestroy(w->step_graph); w->step_graph = nullptr; }
@@ -425,6 +429,50 @@ extern "C" int mia_whisper_align(mia_whisper* w, const int32_t* tokens, int stri
       for (int t = 0; t < ntok[b]; ++t)
         for (int f2 = 0; f2 < T; ++f2) matrix[((size_t)b * stride + t) * T + f2] = f2 < nfr[b] ? -cost[((size_t)b * C + t) * T + f2] : 0.f;
   }
+  return MIA_OK;
+}
+
+// ---- test hooks ---------------------------------------------------------------------------------------------------------------------
+extern "C" int mia_whisper_set_debug(mia_whisper* w, int flags) {
+  if (!w) return MIA_ERR_MODEL_NOT_LOADED;
+  MIA_CHECK_ARG(w->ctx, flags >= 0 && flags <= 3, "set_debug: flags must be 0..3 (got %d)", flags);
+  w->debug_flags = flags;
+  return MIA_OK;
+}
+
+extern "C" int mia_whisper_trace_logits(mia_whisper* w, const int32_t* clips, int n_clips) {
+  if (!w) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = w->ctx;
+  MIA_CHECK_ARG(ctx, n_clips >= 0 && n_clips <= 8 && (n_clips == 0 || clips), "trace_logits: 0..8 clips");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  w->graph_valid = false;                      // the captured graphs hold the old trace pointers
+  if (w->trace) { (void)hipFree(w->trace); w->trace = nullptr; }
+  if (w->trace_clips) { (void)hipFree(w->trace_clips); w->trace_clips = nullptr; }
+  w->trace_n = 0;
+  w->trace_clip_ids.clear();
+  if (n_clips == 0) return MIA_OK;
+  for (int i = 0; i < n_clips; ++i) MIA_CHECK_ARG(ctx, clips[i] >= 0, "trace_logits: negative clip index");
+  const size_t bytes = (size_t)n_clips * w->dims.n_text_ctx * w->dims.n_vocab * sizeof(float);
+  if (hipMalloc((void**)&w->trace, bytes) != hipSuccess) { w->trace = nullptr; return mia_fail(ctx, MIA_ERR_OUT_OF_MEMORY, "trace_logits: hipMalloc(%zu) failed", bytes); }
+  if (hipMalloc((void**)&w->trace_clips, (size_t)n_clips * 4) != hipSuccess) { (void)hipFree(w->trace); w->trace = nullptr; w->trace_clips = nullptr; return mia_fail(ctx, MIA_ERR_OUT_OF_MEMORY, "trace_logits: hipMalloc failed"); }
+  MIA_HIP(ctx, hipMemsetAsync(w->trace, 0xff, bytes, ctx->stream));       // NaN pattern: an unwritten row cannot pass a comparison
+  MIA_HIP(ctx, hipMemcpyAsync(w->trace_clips, clips, (size_t)n_clips * 4, hipMemcpyHostToDevice, ctx->stream));
+  MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  w->trace_n = n_clips;
+  w->trace_clip_ids.assign(clips, clips + n_clips);
+  return MIA_OK;
+}
+
+extern "C" int mia_whisper_read_logit_trace(mia_whisper* w, int slot, int first_pos, int n_pos, float* out) {
+  if (!w) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = w->ctx;
+  MIA_CHECK_ARG(ctx, w->trace && slot >= 0 && slot < w->trace_n, "read_logit_trace: no trace for slot %d", slot);
+  MIA_CHECK_ARG(ctx, out && first_pos >= 0 && n_pos > 0 && first_pos + n_pos <= w->dims.n_text_ctx, "read_logit_trace: bad position range");
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t V = w->dims.n_vocab;
+  MIA_HIP(ctx, hipMemcpyAsync(out, w->trace + ((size_t)slot * w->dims.n_text_ctx + first_pos) * V, (size_t)n_pos * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MIA_OK;
 }
 

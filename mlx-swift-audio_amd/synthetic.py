@@ -95,25 +95,44 @@ def synthetic_weights(d: ModelDimensions, seed: int = 0, style: str = "lecun", r
     """Seeded random-init checkpoint with the reference's key schema.
     style 'survey': N(0, 0.02^2) matrices, LN gamma 1 beta 0.
     style 'lecun' : N(0, 1/fan_in) matrices, small random biases / LN affine -- O(1) activations, harder test.
+    style 'peaky' : 'lecun' re-balanced so that greedy decoding is NOT degenerate (with tied embeddings a random checkpoint repeats one
+                    token: the residual stream is dominated by the embedding of the token just fed, whose own logit |e_t|^2 then wins):
+                    the final decoder LayerNorm gain gets a random sign per channel (the tied projection of e_t onto itself becomes a
+                    zero-mean sum), embedding rows are unit vectors with log-normal gains (a heavy-tailed logit distribution: top-2
+                    margins far above the 16-bit rounding noise, softmax peaked enough that the timestamp heuristic does not mask every
+                    step), decoder query / key matrices x2 (peaked attention: the output depends on WHICH frames / earlier tokens are
+                    attended), positional rows N(0, 0.3^2), conv1 x6 (audio content outweighs the sinusoidal positions).  The result
+                    depends on the clip, the position and the token history; tests assert that on the oracle's run.
     round_to: None | 'bf16' | 'f16' rounds every tensor to that storage type (still returned as fp32)."""
     w: dict[str, np.ndarray] = {}
+    peaky = style == "peaky"
     for name, shape in weight_names(d).items():
         rng = np.random.Generator(np.random.PCG64(_key_seed(name, seed)))
         is_ln = "_ln." in name or ".ln." in name or "ln_post" in name
         if is_ln and name.endswith(".weight"):
             a = np.ones(shape, np.float32) if style == "survey" else (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+            if peaky and name == "decoder.ln.weight":
+                a = a * np.where(rng.random(shape) < 0.5, -1.0, 1.0).astype(np.float32)
         elif name.endswith(".bias"):
             a = np.zeros(shape, np.float32) if style == "survey" else (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif peaky and name == "decoder.token_embedding.weight":
+            a = rng.standard_normal(shape, dtype=np.float32)
+            a /= np.linalg.norm(a, axis=1, keepdims=True)
+            a *= np.exp(0.5 * rng.standard_normal(shape[0])).astype(np.float32)[:, None]
         else:
             if style == "survey":
                 std = 0.02
             elif name == "decoder.token_embedding.weight":
                 std = 1.0 / math.sqrt(shape[-1]) * 4.0     # spread logits: larger argmax margins
             elif name == "decoder.positional_embedding":
-                std = 0.02
+                std = 0.3 if peaky else 0.02
             else:
                 fan_in = int(np.prod(shape[1:]))
                 std = 1.0 / math.sqrt(fan_in)
+                if peaky and name.startswith("decoder.") and (name.endswith("query.weight") or name.endswith("key.weight")):
+                    std *= 2.0
+                if peaky and name == "encoder.conv1.weight":
+                    std *= 6.0
             a = rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
         w[name] = round_array(a, round_to)
     return w

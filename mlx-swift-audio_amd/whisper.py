@@ -167,6 +167,30 @@ class WhisperModel:
         lib.mia_whisper_set_gemm_variant.argtypes = [C.c_void_p, C.c_int]
         self.ctx.check(lib.mia_whisper_set_gemm_variant(self.h, int(variant)))
 
+    def set_debug(self, flags: int) -> None:
+        """Test hook (mia_whisper_set_debug): bit 0 = no hipGraph, bit 1 = one-workgroup head."""
+        lib = self.ctx.lib
+        lib.mia_whisper_set_debug.restype = C.c_int
+        lib.mia_whisper_set_debug.argtypes = [C.c_void_p, C.c_int]
+        self.ctx.check(lib.mia_whisper_set_debug(self.h, int(flags)))
+
+    def trace_logits(self, clips: list[int]) -> None:
+        """Test hook (mia_whisper_trace_logits): keep the raw step logits of these batch rows; [] switches the trace off."""
+        lib = self.ctx.lib
+        lib.mia_whisper_trace_logits.restype = C.c_int
+        lib.mia_whisper_trace_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        a = np.asarray(clips, np.int32)
+        self.ctx.check(lib.mia_whisper_trace_logits(self.h, a.ctypes.data if a.size else None, int(a.size)))
+
+    def read_logit_trace(self, slot: int, first_pos: int, n_pos: int) -> np.ndarray:
+        """Rows [first_pos, first_pos + n_pos) of trace slot `slot`: float32 [n_pos, n_vocab]."""
+        lib = self.ctx.lib
+        lib.mia_whisper_read_logit_trace.restype = C.c_int
+        lib.mia_whisper_read_logit_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        out = np.empty((n_pos, self.dims.n_vocab), np.float32)
+        self.ctx.check(lib.mia_whisper_read_logit_trace(self.h, slot, first_pos, n_pos, out.ctypes.data))
+        return out
+
     def clone(self, ctx: "_lib.Context") -> "WhisperModel":
         """A second handle on the same weights with its own batch state, bound to `ctx` (another stream of the same device)."""
         lib = ctx.lib

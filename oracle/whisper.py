@@ -228,6 +228,8 @@ class DecodingResult:
     no_speech_prob: float
     margins: list[float]          # oracle-only diagnostic: top-1 minus top-2 filtered logit at every step
     initial_tokens: list[int]
+    heur: list = None             # oracle-only diagnostic: ts_logprob - max_text_logprob of the raw-logit timestamp heuristic (None where
+                                  # it does not run): the decision flips when this crosses 0
     cdf_margins: list = None      # oracle-only diagnostic (T > 0): distance of the step's uniform to the nearest edge of the chosen
                                   # token's CDF interval, i.e. how far the 16-bit build's CDF may move before the draw changes
 
@@ -292,11 +294,32 @@ def rule_masks(tokens: list[int], initial_count: int, st: SpecialTokens, o: Deco
     return base, ts_mask
 
 
+def filter_logits(last: torch.Tensor, tokens: list[int], initial_count: int, st: SpecialTokens, o: DecodingOptions):
+    """One iteration's logit rules (WhisperDecoding.swift:186-330) on the raw logits `last` [V] of the position that predicts the next
+    token, given the sequence so far: suppress / timestamp-rule masks, then the timestamp-probability heuristic evaluated on the RAW
+    logits (:299-322).  Returns (filtered logits, heuristic distance) -- the distance ts_logprob - max_text_logprob is what the
+    heuristic thresholds at 0 (None when the heuristic does not run)."""
+    V = last.shape[-1]
+    NEG = -float("inf")
+    idx = torch.arange(V)
+    num_generated = len(tokens) - initial_count
+    base, ts_mask = rule_masks(tokens, initial_count, st, o, V)
+    tsb = st.timestamp_begin
+    dist = None
+    if o.timestamps and num_generated > 0:                           # :299-322 on RAW logits
+        lp = last - torch.logsumexp(last, dim=-1, keepdim=True)
+        ts_lp = torch.logsumexp(lp[tsb:], dim=-1)
+        max_text = lp[:tsb].max()
+        dist = float(ts_lp) - float(max_text)
+        if float(ts_lp) > float(max_text):
+            ts_mask[idx < tsb] = NEG
+    return last + torch.minimum(base, ts_mask), dist
+
+
 def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: DecodingOptions, uniforms=None) -> DecodingResult:
     """GreedyDecoder.decode (WhisperDecoding.swift:96-389) for ONE clip (xa [1, n_audio_ctx, D]).  temperature 0 = argmax;
     temperature > 0 samples with `uniforms[k]` standing in for the k-th Float.random(in: 0..<1) of the reference."""
     assert o.temperature == 0.0 or uniforms is not None, "T>0 needs explicit uniforms (the reference's RNG is unseeded)"
-    V = model.dims.n_vocab
     tokens, sot_index = initial_tokens(st, o)
     init = list(tokens)
     initial_count = len(tokens)
@@ -307,28 +330,15 @@ def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: 
     sum_lp, count, no_speech_prob = 0.0, 0, 0.0
     margins: list[float] = []
     cdf_margins: list[float] = []
-    NEG = -float("inf")
-    idx = torch.arange(V)
+    heur: list = []
     for it in range(max_generate):
         feed = tokens if kv is None else tokens[-1:]
         logits, kv = model.decode(feed, xa, kv)
         if it == 0:
             probs = torch.softmax(logits[0, sot_index], dim=-1)          # :158-169
             no_speech_prob = float(probs[st.no_speech])
-        last = logits[0, -1].clone()
-        num_generated = len(tokens) - initial_count
-        base, ts_mask = rule_masks(tokens, initial_count, st, o, V)
-        tsb = st.timestamp_begin
-        force_ts = False
-        if o.timestamps and num_generated > 0:                           # :299-322 on RAW logits
-            lp = last - torch.logsumexp(last, dim=-1, keepdim=True)
-            ts_lp = torch.logsumexp(lp[tsb:], dim=-1)
-            max_text = lp[:tsb].max()
-            if float(ts_lp) > float(max_text):
-                force_ts = True
-        if force_ts:
-            ts_mask[idx < tsb] = NEG
-        last = last + torch.minimum(base, ts_mask)
+        last, hd = filter_logits(logits[0, -1].clone(), tokens, initial_count, st, o)
+        heur.append(hd)
         cdf_m = float("inf")
         if o.temperature == 0.0:
             nxt = int(torch.argmax(last))
@@ -354,7 +364,34 @@ def greedy_decode(model: WhisperOracle, st: SpecialTokens, xa: torch.Tensor, o: 
     gen = tokens[initial_count:]
     if st.eot in gen:
         gen = gen[:gen.index(st.eot)]
-    return DecodingResult(gen, avg, no_speech_prob, margins, init, cdf_margins)
+    return DecodingResult(gen, avg, no_speech_prob, margins, init, heur, cdf_margins)
+
+
+def teacher_forced_logits(model: WhisperOracle, xa: torch.Tensor, tokens: list[int]) -> np.ndarray:
+    """Raw logits [len(tokens), V] of ONE causal pass over `tokens` (TextDecoder.swift:53-96 without a cache): row p is what the
+    decoder predicts after consuming tokens[0..p] -- the quantity a step-by-step decoder with a KV cache computes at position p."""
+    logits, _ = model.decode(list(tokens), xa)
+    return logits[0].numpy()
+
+
+def replay_rules(step_logits: np.ndarray, tokens: list[int], initial_count: int, st: SpecialTokens, o: DecodingOptions):
+    """Run the decode head's decision logic (filter_logits + argmax + log-prob bookkeeping, WhisperDecoding.swift:186-350) on GIVEN
+    per-position raw logits (row p predicts tokens[p + 1]) along the GIVEN token sequence: what a decoder whose logits these are must
+    have emitted.  Returns (ids per generated position, margins, heuristic distances, avg_logprob)."""
+    ids, margins, dists = [], [], []
+    sum_lp, count = 0.0, 0
+    for p in range(initial_count - 1, len(tokens) - 1):
+        last, dist = filter_logits(torch.from_numpy(np.ascontiguousarray(step_logits[p], np.float32)).clone(), list(tokens[:p + 1]), initial_count, st, o)
+        nxt = int(torch.argmax(last))
+        top2 = torch.topk(last, 2).values
+        margins.append(float(top2[0] - top2[1]))
+        dists.append(dist)
+        ids.append(nxt)
+        emitted = tokens[p + 1]
+        if emitted != st.eot:
+            sum_lp += float(torch.log(torch.softmax(last, dim=-1))[emitted])
+            count += 1
+    return ids, margins, dists, (sum_lp / count if count else 0.0)
 
 
 # ---- word timestamps: WhisperTiming.swift (dtw :46-130, medianFilterAttention :191-253, findAlignment :558-748) ----------------------

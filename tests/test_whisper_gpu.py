@@ -3,8 +3,10 @@
 Both sides use the same seeded synthetic checkpoint, pre-rounded to the 16-bit storage type so only activation
 precision and accumulation order differ.  Tolerances (stated, checked below):
   audio features (post-LayerNorm, O(1)):  max |err| <= 0.06 (bf16) / 0.01 (f16); mean |err| <= 0.008 / 0.0015
-  greedy token ids: bit-exact, except that a first divergence is tolerated only where the oracle's own top-1/top-2
-  margin is below MARGIN_TOL (a near-tie that 16-bit activations cannot resolve); the golden case must match fully.
+  greedy token ids: f16 -- bit-exact for whole runs on non-degenerate checkpoints (tests/test_whisper_steps_gpu.py, test_golden.py);
+  bf16 -- logits at every position + exact head replay + explained forks (tests/_whisper_trace.py).  The remaining tests here
+  (prompt conditioning, ragged prefixes, sampling) keep the margin rule: a first divergence is tolerated only where the oracle's
+  own top-1/top-2 margin is below MARGIN_TOL (a near-tie that 16-bit activations cannot resolve).
   sampled (T > 0) ids: same rule with the oracle's CDF-edge distance (CDF_TOL) in place of the logit margin.
 """
 import numpy as np
@@ -83,30 +85,40 @@ def _compare(tokens, ref, tol):
     return None, None
 
 
-@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
-@pytest.mark.parametrize("timestamps", [True, False])
-def test_greedy_decode_matches_oracle(ctx, dtype_name, timestamps):
+@pytest.mark.parametrize("dims_name,timestamps,seed", [("micro.en", True, 77), ("micro", False, 157)])
+def test_greedy_decode_bf16_matches_oracle(ctx, dims_name, timestamps, seed):
+    """bf16 (the benchmark's storage type) on the non-degenerate 'peaky' checkpoints of tests/test_whisper_steps_gpu.py (which holds
+    the f16 bit-exact-id runs): bf16 logit noise (~1e-2 of the logit spread) is too large for 256 consecutive argmax decisions to be
+    separated from it, so parity is stated as in tests/_whisper_trace.py -- the step graph's logits of every clip within the bf16
+    tolerance of the oracle's at every position, the head's decisions replayed exactly on them, and a split from the oracle's free
+    run legal only where the two measured logit errors cover the oracle's margin (or flip its timestamp heuristic)."""
     from mlx_swift_audio_amd import whisper as HW
-    dims, oracle, model = _models(ctx, "micro.en", dtype_name, seed=5)
+    from _whisper_trace import assert_fork_explained, check_clip, first_fork, nondegenerate
+    dims = OW.DIMS[dims_name]
+    weights = OW.synthetic_weights(dims, seed=seed, style="peaky", round_to="bf16")
+    oracle = OW.WhisperOracle(dims, weights)
+    model = HW.WhisperModel.load(ctx, dims, weights, _dt("bf16"))
     st = OW.SpecialTokens.for_vocab(dims.n_vocab)
     sup = OW.synthetic_suppress_list(st)
-    B = 4
-    mel = _mel(dims, B, 1, dtype_name)
-    o = HW.DecodingOptions(timestamps=timestamps, suppress_ids=sup, blank_ids=[220, 50256 - 1], max_new_tokens=40)
-    res = HW.GreedyDecoder(model, o).decode(mel)
-    oo = OW.DecodingOptions(timestamps=timestamps, suppress_ids=sup, blank_ids=[220, 50256 - 1], max_new_tokens=40)
+    B, n_new = 4, 64
+    mel = _mel(dims, B, 1, "bf16")
+    kw = dict(timestamps=timestamps, suppress_ids=sup, blank_ids=[220, 50256 - 1], max_new_tokens=n_new)
+    model.trace_logits(list(range(B)))
+    res = HW.GreedyDecoder(model, HW.DecodingOptions(**kw)).decode(mel)
+    oo = OW.DecodingOptions(**kw)
     xa = oracle.encode(mel)
+    refs = [OW.greedy_decode(oracle, st, xa[b:b + 1], oo) for b in range(B)]
+    nondegenerate(refs, n_new, min_distinct=10)
     full = 0
     for b in range(B):
-        ref = OW.greedy_decode(oracle, st, xa[b:b + 1], oo)
-        i, margin = _compare(res[b].tokens, ref, MARGIN_TOL[dtype_name])
-        if i is None:
+        info = check_clip(model, oracle, st, oo, res[b], b, xa[b:b + 1], "bf16", n_new, tol_scale=1.5)    # end to end: the bf16 encoder's error is in
+        k = first_fork(res[b].tokens, refs[b].tokens)
+        if k is None:
             full += 1
-            np.testing.assert_allclose(res[b].avg_logprob, ref.avg_logprob, atol=0.05, rtol=0.02)
+            np.testing.assert_allclose(res[b].avg_logprob, refs[b].avg_logprob, atol=0.05, rtol=0.02)
         else:
-            assert margin < MARGIN_TOL[dtype_name], f"clip {b}: diverged at step {i} where the oracle margin is {margin}"
-        np.testing.assert_allclose(res[b].no_speech_prob, ref.no_speech_prob, rtol=0.1, atol=1e-6)
-    assert full >= 1, "no clip matched the oracle end to end"
+            assert_fork_explained(info, refs[b], k)
+        np.testing.assert_allclose(res[b].no_speech_prob, refs[b].no_speech_prob, rtol=0.1, atol=1e-6)
     model.close()
 
 
