@@ -40,8 +40,9 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(dims_name: str, seed: int, n_threads: int, max_new_tokens: int):
-    """fp32 CPU restatement of the same pipeline on ONE of the clips (bounded sample), all stages timed."""
+def cpu_baseline(dims_name: str, seed: int, n_threads: int, max_new_tokens: int, repeats: int = 3):
+    """fp32 CPU restatement of the same pipeline on ONE of the clips (bounded sample), all stages timed; `repeats` complete runs,
+    the MEDIAN is reported (one sample right after GPU work swung 2.1 -> 1.7 audio-s/s between rounds) and every run is listed."""
     import torch
     from oracle import logmel as OL
     from oracle import whisper as OW
@@ -51,33 +52,59 @@ def cpu_baseline(dims_name: str, seed: int, n_threads: int, max_new_tokens: int)
     weights = OW.synthetic_weights(dims, seed=seed, style="survey", round_to="bf16")
     model = OW.WhisperOracle(dims, weights)
     clip = OL.synth_clip(0)
-    t0 = time.perf_counter()
-    mel = OL.whisper_log_mel_spectrogram(clip, dims.n_mels, padding=OL.N_SAMPLES)[:OL.N_FRAMES]
-    mel = OW.round_array(mel, "bf16")[None]
-    t1 = time.perf_counter()
-    xa = model.encode(mel)
-    t2 = time.perf_counter()
     o = OW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=max_new_tokens)
-    r = OW.greedy_decode(model, st, xa, o)
-    t3 = time.perf_counter()
-    n_tok = max(len(r.margins), 1)
-    full_tokens = dims.n_text_ctx - len(r.initial_tokens)
-    # decode is linear in the number of steps: scale the measured steps to the full 445-step budget the GPU run executes
-    t_dec_full = (t3 - t2) * full_tokens / n_tok
-    total = (t1 - t0) + (t2 - t1) + t_dec_full
-    return {"value": 30.0 / total, "unit": "audio-sec/s", "cores": n_threads, "kind": "port",
-            "sample": (f"1 of the 30 s clips, fp32 torch-CPU restatement (oracle/): log-mel {t1 - t0:.2f}s + encoder {t2 - t1:.2f}s + "
-                       f"{n_tok} greedy steps {t3 - t2:.2f}s scaled to {full_tokens} steps")}
+    runs = []
+    for _ in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        mel = OL.whisper_log_mel_spectrogram(clip, dims.n_mels, padding=OL.N_SAMPLES)[:OL.N_FRAMES]
+        mel = OW.round_array(mel, "bf16")[None]
+        t1 = time.perf_counter()
+        xa = model.encode(mel)
+        t2 = time.perf_counter()
+        r = OW.greedy_decode(model, st, xa, o)
+        t3 = time.perf_counter()
+        n_tok = max(len(r.margins), 1)
+        full_tokens = dims.n_text_ctx - len(r.initial_tokens)
+        # decode is linear in the number of steps: scale the measured steps to the full 445-step budget the GPU run executes
+        t_dec_full = (t3 - t2) * full_tokens / n_tok
+        runs.append((30.0 / ((t1 - t0) + (t2 - t1) + t_dec_full), t1 - t0, t2 - t1, t3 - t2, n_tok, full_tokens))
+    runs.sort()
+    v, a, b, c, n_tok, full_tokens = runs[len(runs) // 2]
+    return {"value": round(v, 3), "unit": "audio-sec/s", "cores": n_threads, "kind": "port",
+            "sample": (f"1 of the 30 s clips, fp32 torch-CPU restatement (oracle/), median of {len(runs)} complete runs "
+                       f"({', '.join('%.2f' % r[0] for r in runs)} audio-sec/s): log-mel {a:.2f}s + encoder {b:.2f}s + "
+                       f"{n_tok} greedy steps {c:.2f}s scaled to {full_tokens} steps")}
+
+
+def visible_gpu_count() -> int:
+    """GPUs this process may use, WITHOUT touching the HIP runtime (the launcher must stay HIP-free: it spawns the ranks): the KFD
+    topology lists one node per agent, GPUs are the nodes with simd_count > 0; ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES narrow the set like they do for the runtime."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def self_launch(n: int) -> int:
-    """Start n rank processes of this script on one node and wait for them; rank 0's JSON line goes to our stdout."""
+    """Start n rank processes of this script on one node (plain child processes, subprocess.Popen -- not torch.distributed.run) and
+    wait for them; rank 0's JSON line goes to our stdout.  This launcher never initialises HIP: devices are counted from sysfs."""
     import socket
     import subprocess
+    dry = "--dry-run" in sys.argv
     rehearsal = os.environ.get("MIA_BENCH_REHEARSAL") == "1"
-    if not rehearsal:
-        import torch
-        have = torch.cuda.device_count()
+    if not rehearsal and not dry:
+        have = visible_gpu_count()
         if have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
             return 2
@@ -90,10 +117,124 @@ def self_launch(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+    rcs = [p.wait() for p in procs]
+    for r, c in enumerate(rcs):
+        if c != 0:
+            print(f"bench.py: rank {r} exited with code {c}", file=sys.stderr)
+    return max(abs(c) for c in rcs)
+
+
+class Exchanger:
+    """The ONE exchange channel of a rank (one all-gather of token ids per pass).  With R replicas decoding on R streams
+    from R host threads, letting every replica issue its own collective would make the order of collectives timing-dependent and
+    different from rank to rank -- the documented deadlock shape of NCCL-family libraries.  Here every rank deals pass i to replica
+    i % R, ONE thread per rank issues the gathers strictly in pass order 0, 1, 2, ... on ONE communicator / stream, and a gather
+    waits (stream-side) on the event its pass recorded behind the decode.  Same order on every rank by construction."""
+
+    def __init__(self, issue):
+        import threading
+        self.issue = issue                   # issue(payload): enqueue ONE gather on the exchange stream (never blocks on the GPU)
+        self.cv = threading.Condition()
+        self.pending = {}
+        self.next = 0
+        self.stop_at = None
+        self.error = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+        self.order = []                      # pass ids in the order issued (asserted == 0, 1, 2, ... by the tests)
+
+    def submit(self, pass_id, payload):
+        with self.cv:
+            self.pending[pass_id] = payload
+            self.cv.notify_all()
+
+    def _run(self):
+        while True:
+            with self.cv:
+                while self.next not in self.pending and (self.stop_at is None or self.next < self.stop_at):
+                    self.cv.wait()
+                if self.next not in self.pending:
+                    return
+                payload = self.pending.pop(self.next)
+            try:
+                self.issue(payload)
+            except BaseException as e:       # surface in close(); keep consuming so that no submitter waits forever
+                self.error = self.error or e
+            self.order.append(self.next)
+            with self.cv:
+                self.next += 1
+                self.cv.notify_all()
+
+    def wait_issued(self, pass_id):
+        """Block (host side) until the gather of `pass_id` has been enqueued."""
+        with self.cv:
+            while self.next <= pass_id:
+                self.cv.wait()
+
+    def close(self, n_passes):
+        with self.cv:
+            self.stop_at = n_passes
+            self.cv.notify_all()
+        self.thread.join()
+        if self.error:
+            raise self.error
+
+
+def dry_run(args, rank, world):
+    """Control flow of an N-rank run WITHOUT a GPU (tests/test_multi_rank.py): R replica threads per rank 'decode' passes (they write
+    rank- and pass-stamped token rows after a jittered sleep, so ranks and replicas finish in different orders), the Exchanger issues
+    one gloo all-gather per pass in pass order, every rank checks every gathered row.  Prints the contract's JSON line with
+    data = 'dry-run'."""
+    import random
+    import threading
+    import torch
+    import torch.distributed as dist
+    from mlx_swift_audio_amd import parallel as P
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, L, R = args.batch, 448, max(1, min(args.replicas, args.steps))
+    total = args.warmup * R + args.steps
+    got = {}
+
+    def issue(payload):
+        pid, toks, cnt = payload
+        got[pid] = P.gather_tokens(toks, cnt, world, max_shard=B) if world > 1 else (toks, cnt)
+
+    ex = Exchanger(issue)
+    rnd = random.Random(1000 * rank + 7)
+
+    def replica(r):
+        for pid in range(r, total, R):
+            time.sleep(rnd.random() * 0.02)
+            toks = torch.full((B, L), 1000 * pid + rank, dtype=torch.int32)
+            toks[:, 0] = torch.arange(B, dtype=torch.int32)
+            ex.submit(pid, (pid, toks, torch.full((B,), pid % 7, dtype=torch.int32)))
+            ex.wait_issued(pid)                       # the replica's buffers are free again once its gather has been enqueued
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=replica, args=(r,)) for r in range(R)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    ex.close(total)
+    elapsed = time.perf_counter() - t0
+    assert ex.order == list(range(total)), ex.order
+    for pid in range(total):
+        toks, cnt = got[pid]
+        assert toks.shape == (B * world, L) and cnt.shape == (B * world,)
+        for rk in range(world):
+            blk = toks[rk * B:(rk + 1) * B]
+            assert bool((blk[:, 1:] == 1000 * pid + rk).all()) and bool((blk[:, 0] == torch.arange(B, dtype=torch.int32)).all()), (pid, rk)
+        assert bool((cnt == pid % 7).all())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "audio-sec/s (Whisper large-v3-turbo b=32) at 1/2/4/8 GPU; codec samples/s", "value": 0.0, "unit": "audio-sec/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(total, 1) * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "dry-run (no GPU work: launcher + exchange order only)",
+                          "config": {"workload": "dry-run", "replicas": R, "passes_exchanged": total, "exchange_order_ok": True}}), flush=True)
 
 
 def config0_leg(ctx, torch, dtype_name: str = "f16"):
@@ -136,39 +277,99 @@ def config0_leg(ctx, torch, dtype_name: str = "f16"):
 
 
 def lm_bench(ctx, torch, name: str, batch: int):
-    """BASELINE.json configs[2] ("Orpheus-3B TTS: Llama-3 backbone autoregress + SNAC codec decode"), the LM half: random-init bf16
-    weights, 64-token prompts, 210 sampled tokens (30 SNAC frames); one sequence, then `batch` sentences side by side.  Host-inclusive
-    wall clock (the loop lives behind the C ABI; only the early-exit poll touches the host)."""
+    """BASELINE.json configs[2] ("Orpheus-3B TTS: Llama-3 backbone autoregress + SNAC codec decode"), the LM half, and configs[3]'s
+    Qwen2LM: random-init weights, 64-token prompts, 210 sampled tokens (30 SNAC frames); one sequence on bf16 weights and on packed
+    MLX-affine 4-bit weights (the reference's default checkpoint format, OrpheusWeightLoader.swift:28-60; for the TIMING leg the packed
+    codes / scales are random words of the right shape -- quantising 3.3 G weights in numpy would take minutes and changes no byte
+    count; the bit-identity of the packed step with the expanded checkpoint is tests/test_lm_gpu.py's job), then `batch` sentences side
+    by side.  ms_per_token excludes the prompt pass; frac = algorithmic weight bytes per token / time / 8 TB/s."""
     from mlx_swift_audio_amd import lm as HL
     from mlx_swift_audio_amd import synthetic as S
     import mlx_swift_audio_amd as m
     cfg = S.LM_CONFIGS[name]
-    model = HL.CausalLM.load(ctx, cfg, S.lm_weights(cfg, seed=0, dtype=np.float16), m.BF16)
+    t0 = time.time()
+    w = S.lm_weights(cfg, seed=0, dtype=np.float16)
+    model = HL.CausalLM.load(ctx, cfg, w, m.BF16)
     rng = np.random.default_rng(0)
+    lin = (["model.embed_tokens"] if cfg.tie_embeddings else ["lm_head"])
+    for l in range(cfg.n_layers):
+        lin += [f"model.layers.{l}.self_attn.{n}_proj" for n in "qkvo"] + [f"model.layers.{l}.mlp.{n}_proj" for n in ("gate", "up", "down")]
+    packed = {}
+    for n in lin:
+        N, K = w[n + ".weight"].shape
+        packed[n + ".weight"] = rng.integers(0, 1 << 32, (N, K // 8), dtype=np.uint32)
+        packed[n + ".scales"] = np.full((N, K // 64), 0.004, np.float16)
+        packed[n + ".biases"] = np.full((N, K // 64), -0.03, np.float16)
+    del w
+    model.attach_q4(packed)
+    del packed
+    log(f"[bench] {name} checkpoint (bf16 + packed q4) ready in {time.time() - t0:.1f}s")
     n_new, n_prompt = 210, 64
     stop = (cfg.vocab - 1,)
     prompt = rng.integers(0, min(128000, cfg.vocab), n_prompt).tolist()
     u = rng.random(n_new).astype(np.float32)
-    model.generate(prompt, u, max_new_tokens=16, stop_ids=stop)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    gen = model.generate(prompt, u, max_new_tokens=n_new, stop_ids=stop)
-    d1 = time.perf_counter() - t0
     params = cfg.vocab * cfg.hidden + cfg.n_layers * ((cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim * cfg.hidden + cfg.hidden * cfg.n_heads * cfg.head_dim + 3 * cfg.inter * cfg.hidden)
-    res = {"model": name, "prompt_tokens": n_prompt, "generated_tokens": len(gen), "tokens_per_s": round(len(gen) / d1, 1), "ms_per_token_incl_prompt": round(d1 / len(gen) * 1e3, 3),
-           "weight_GB_per_token": round(2.0 * params / 1e9, 3), "hbm_GBs": round(2.0 * params * len(gen) / d1 / 1e9, 1)}
-    if batch > 1:
-        model.set_batch(batch)
-        prompts = [rng.integers(0, min(128000, cfg.vocab), n_prompt).tolist() for _ in range(batch)]
-        ub = rng.random((batch, n_new)).astype(np.float32)
-        model.generate_batch(prompts, ub, max_new_tokens=16, stop_ids=stop)
+
+    def one(q4: bool):
+        model.use_q4(q4)
+        model.generate(prompt, u, max_new_tokens=16, stop_ids=stop)          # graph capture for this weight format
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        outs = model.generate_batch(prompts, ub, max_new_tokens=n_new, stop_ids=stop)
-        db = time.perf_counter() - t0
-        ntok = sum(len(o) for o in outs)
-        res["batched"] = {"sequences": batch, "tokens_per_s": round(ntok / db, 1), "audio_seconds_per_second": round(ntok / 7 * 2048 / 24000.0 / db, 1)}
+        model.generate(prompt, u, max_new_tokens=1, stop_ids=stop)           # batched prompt pass + the first step
+        d_prompt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        gen = model.generate(prompt, u, max_new_tokens=n_new, stop_ids=stop)
+        dt = time.perf_counter() - t0
+        steps = len(gen) - 1
+        bytes_tok = params * (0.5 + 4.0 / 64) if q4 else 2.0 * params        # q4: 4 bits + (scale, bias) 2 x 16 bit per 64 weights
+        ms = (dt - d_prompt) / max(steps, 1) * 1e3
+        r = {"weights": "mlx-affine q4 g64, packed step" if q4 else "bf16", "generated_tokens": len(gen), "prompt_pass_plus_first_step_ms": round(d_prompt * 1e3, 2),
+             "ms_per_token": round(ms, 4), "tokens_per_s": round(1e3 / ms, 1), "weight_GB_per_token": round(bytes_tok / 1e9, 3),
+             "GBs_algorithmic": round(bytes_tok / (ms * 1e-3) / 1e9, 1), "frac": round(bytes_tok / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if batch > 1:
+            model.set_batch(batch)
+            prompts = [rng.integers(0, min(128000, cfg.vocab), n_prompt).tolist() for _ in range(batch)]
+            ub = rng.random((batch, n_new)).astype(np.float32)
+            model.generate_batch(prompts, ub, max_new_tokens=16, stop_ids=stop)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            outs = model.generate_batch(prompts, ub, max_new_tokens=n_new, stop_ids=stop)
+            db = time.perf_counter() - t0
+            ntok = sum(len(o) for o in outs)
+            r["batched"] = {"sequences": batch, "tokens_per_s": round(ntok / db, 1), "audio_seconds_per_second": round(ntok / 7 * 2048 / 24000.0 / db, 1)}
+            model.set_batch(1)
+        return r
+
+    res = {"model": name, "prompt_tokens": n_prompt, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "bf16": one(False), "q4": one(True)}
     model.close()
+    # ---- CosyVoice2's Qwen2LM (configs[3]): Qwen2-0.5B backbone, 300 prompt rows -> 300 speech tokens (12 s), RAS sampler
+    try:
+        qcfg = S.LM_CONFIGS["qwen2-0.5b"]
+        qw = S.lm_weights(qcfg, seed=0, dtype=np.float16)
+        qw.update(S.qwen2lm_extra_weights(qcfg, 6561, seed=0))
+        qm = HL.CausalLM.load(ctx, qcfg, qw, m.BF16)
+        del qw
+        n_rows, n_gen = 300, 300
+        x = rng.standard_normal((n_rows, qcfg.hidden)).astype(np.float32)
+        uq = rng.random(4 * n_gen + 64).astype(np.float32)
+
+        def run(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = qm.generate_ras(x, uq, n, n, 6561)
+            return time.perf_counter() - t0, out
+        run(8)
+        d1, _ = run(1)
+        dt, out = run(n_gen)
+        qparams = 6564 * qcfg.hidden + qcfg.n_layers * ((qcfg.n_heads + 2 * qcfg.n_kv_heads) * qcfg.head_dim * qcfg.hidden + qcfg.hidden * qcfg.n_heads * qcfg.head_dim + 3 * qcfg.inter * qcfg.hidden)
+        ms = (dt - d1) / max(len(out) - 1, 1) * 1e3
+        res["qwen2lm"] = {"model": "qwen2-0.5b backbone + llm_decoder head (Qwen2LM.inference)", "weights": "bf16", "prompt_rows": n_rows, "generated_tokens": len(out),
+                          "prompt_pass_plus_first_step_ms": round(d1 * 1e3, 2), "ms_per_token": round(ms, 4), "weight_GB_per_token": round(2.0 * qparams / 1e9, 3),
+                          "GBs_algorithmic": round(2.0 * qparams / (ms * 1e-3) / 1e9, 1), "frac": round(2.0 * qparams / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "audio_seconds_per_second": round(len(out) / 25.0 / dt, 1)}
+        qm.close()
+    except Exception as e:
+        res["qwen2lm"] = {"error": repr(e)}
     return res
 
 
@@ -181,6 +382,19 @@ def codec_bench(ctx, torch):
     from mlx_swift_audio_amd import synthetic as S
     res = {}
     rng = np.random.default_rng(7)
+    ctx.lib.mia_profile_codec_bytes.restype = C.c_double
+    ctx.lib.mia_profile_codec_bytes.argtypes = [C.c_int]
+
+    def alg(run, ms):
+        """algorithmic bytes of one call (each fused op's input rows once + outputs once + weights once, counted by the
+        library's launchers: mia_profile_codec_bytes) over the measured time, against the 8 TB/s HBM peak."""
+        ctx.lib.mia_profile_codec_bytes(1)
+        run()
+        b = float(ctx.lib.mia_profile_codec_bytes(1))
+        torch.cuda.synchronize()
+        gbs = b / (ms * 1e-3) / 1e9
+        return {"algorithmic_MB": round(b / 1e6, 1), "GBs_algorithmic": round(gbs, 1), "bound": "hbm", "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
     # ---- SNAC
     cfg = S.SNAC_CONFIGS["snac_24khz"]
     dec = HC.SNACDecoder.load(ctx, cfg, S.snac_weights(cfg, 0))
@@ -208,7 +422,7 @@ def codec_bench(ctx, torch):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     res["snac_24khz_decode"] = {"samples_per_s": round(n_out / (ms * 1e-3), 0), "ms": round(ms, 3), "samples": n_out,
-                                "realtime_factor": round(n_out / 24000.0 / (ms * 1e-3), 1)}
+                                "realtime_factor": round(n_out / 24000.0 / (ms * 1e-3), 1), **alg(run_snac, ms)}
     dec.close()
     # ---- DAC
     dcfg = S.DAC_CONFIGS["dac_speech"]
@@ -230,7 +444,7 @@ def codec_bench(ctx, torch):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     res["dac_speech_decode"] = {"samples_per_s": round(d_out / (ms * 1e-3), 0), "ms": round(ms, 3), "samples": d_out,
-                                "realtime_factor": round(d_out / 24000.0 / (ms * 1e-3), 1)}
+                                "realtime_factor": round(d_out / 24000.0 / (ms * 1e-3), 1), **alg(run_dac, ms)}
     dd.close()
     # ---- HiFT (CosyVoice2 vocoder): 10 s of 50 Hz mel -> 240 000 samples, source noise included as an input
     from mlx_swift_audio_amd import hift as HH
@@ -254,7 +468,7 @@ def codec_bench(ctx, torch):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     res["hift_cosyvoice2_vocode"] = {"samples_per_s": round(h_out / (ms * 1e-3), 0), "ms": round(ms, 3), "samples": h_out,
-                                     "realtime_factor": round(h_out / 24000.0 / (ms * 1e-3), 1)}
+                                     "realtime_factor": round(h_out / 24000.0 / (ms * 1e-3), 1), **alg(run_hift, ms)}
     hg.close()
     # ---- CosyVoice2 flow: 375 new + 150 prompt speech tokens (15 s + 6 s) -> 750 new mel frames, 10 Euler steps with CFG
     from mlx_swift_audio_amd import flow as HFL
@@ -284,7 +498,7 @@ def codec_bench(ctx, torch):
     n_new = Tm - 2 * n_prompt
     res["flow_cosyvoice2_inference"] = {"mel_frames_per_s": round(n_new / (ms * 1e-3), 0), "ms": round(ms, 3), "new_mel_frames": n_new,
                                         "total_frames": Tm, "euler_steps": fcfg.n_timesteps,
-                                        "realtime_factor": round(n_new / 50.0 / (ms * 1e-3), 1)}
+                                        "realtime_factor": round(n_new / 50.0 / (ms * 1e-3), 1), **alg(run_flow, ms)}
     # the same utterance 8 times through ONE pass (mia_flow_inference_batch: stacked, padded sequences; each mel equals the single call)
     import ctypes as C
     U = 8
@@ -331,7 +545,7 @@ def codec_bench(ctx, torch):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     res["s3tokenizer_v2_encode"] = {"tokens_per_s": round(int(sn[0]) / (ms * 1e-3), 0), "ms": round(ms, 3), "mel_frames": Ts, "tokens": int(sn[0]),
-                                    "realtime_factor": round(Ts / 100.0 / (ms * 1e-3), 1)}
+                                    "realtime_factor": round(Ts / 100.0 / (ms * 1e-3), 1), **alg(run_s3, ms)}
     tk.close()
     return res
 
@@ -349,7 +563,9 @@ def main():
     ap.add_argument("--no-codec", action="store_true", help="skip the SNAC/DAC decode samples/s side measurement")
     ap.add_argument("--cpu-tokens", type=int, default=200, help="greedy steps actually run by the CPU baseline (the rest of the 445-step budget is extrapolated linearly)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--lm", default="", help="also time an LM decode loop and add it as `lm` (e.g. orpheus-3b: ~40 s of extra set-up; off by default)")
+    ap.add_argument("--lm", default="orpheus-3b", help="LM decode leg (BASELINE configs[2] / [3]): Orpheus-3B on bf16 and packed MLX-q4 weights + CosyVoice2's Qwen2LM, each with its HBM roofline fraction")
+    ap.add_argument("--no-lm", action="store_true", help="skip the LM leg (~1 min of checkpoint generation)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: only the N-rank launcher + the per-pass exchange order, on gloo (tests/test_multi_rank.py)")
     ap.add_argument("--lm-batch", type=int, default=32, help="sentences side by side in the batched part of --lm")
     ap.add_argument("--replicas", type=int, default=3,
                     help="model replicas on separate HIP streams; passes are dealt round-robin so the encoder of one batch overlaps the decoder of another (1 = strictly serial passes)")
@@ -357,7 +573,7 @@ def main():
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "phased"],
                     help="how R > 1 replicas share the GPU: pipelined = each replica runs whole passes on its own stream; phased = rounds of R passes, all encoders first, then all decoders concurrently")
     ap.add_argument("--no-config0", action="store_true", help="skip the BASELINE configs[0] leg (tiny.en, one 10 s clip: GPU + CPU at all cores and 1 thread)")
-    ap.add_argument("--dp", default="abi", choices=["abi", "torch"], help="token all-gather at N > 1: mia_dp_* (RCCL behind the C ABI, one communicator per replica stream) or torch.distributed")
+    ap.add_argument("--dp", default="abi", choices=["abi", "torch"], help="token all-gather at N > 1: mia_dp_* (RCCL behind the C ABI, ONE communicator on the rank's exchange stream) or torch.distributed")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -366,12 +582,17 @@ def main():
         # initialise the runtime -- so no exec happens after HIP initialisation anywhere.
         raise SystemExit(self_launch(args.gpus))
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # rehearsal hook for a one-GPU box: every rank on device 0 and gloo for the (57 KB) token gather -- the N > 1 control flow without N GPUs
@@ -384,8 +605,6 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
     import mlx_swift_audio_amd as m
     from mlx_swift_audio_amd import synthetic as S
@@ -425,34 +644,41 @@ def main():
                 self.nsp = torch.zeros(B, dtype=torch.float32, device="cuda")
             self.stream.synchronize()
 
-            self.group = None          # torch.distributed group of this replica (fallback exchange)
-            self.dp_abi = False        # mia_dp_* communicator on this replica's context
+            self.pass_done = None      # event recorded behind the last decode on this replica's stream
+            self.last_pass = -1        # id of the last pass this replica submitted to the exchange
             if world > 1:
                 with torch.cuda.stream(self.stream):
                     self.all_tokens = torch.zeros((B * world, self.opts.max_tokens), dtype=torch.int32, device="cuda")
                     self.all_n = torch.zeros(B * world, dtype=torch.int32, device="cuda")
                 self.stream.synchronize()
 
+        def _before(self):
+            # this replica's token buffers are about to be rewritten: its previous pass's gather must have consumed them (stream-side wait)
+            if world > 1 and self.last_pass >= 0:
+                exch.wait_issued(self.last_pass)
+                self.stream.wait_event(self.gather_done)
+
         def step_encode(self):
             self.model.encode_windows_device(pcm.data_ptr(), offs)
 
-        def step_decode(self):
+        def step_decode(self, pass_id):
+            self._before()
             self.model.decode_greedy_device(self.opts, self.tokens.data_ptr(), self.n_tok.data_ptr(), self.avg.data_ptr(), self.nsp.data_ptr())
-            self._exchange()
+            self._exchange(pass_id)
 
-        def step(self):
+        def step(self, pass_id):
+            self._before()
             self.model.transcribe_windows_device(pcm.data_ptr(), offs, self.opts, self.tokens.data_ptr(), self.n_tok.data_ptr(), self.avg.data_ptr(),
                                                  self.nsp.data_ptr())
-            self._exchange()
+            self._exchange(pass_id)
 
-        def _exchange(self):
-            if world > 1:              # the path's only exchange, once per pass, on this pass's buffers, behind the decode on the same stream
-                if self.dp_abi:
-                    P.dp_gather_tokens(self.ctx, self.tokens.data_ptr(), self.n_tok.data_ptr(), B, self.opts.max_tokens, B * world,
-                                       self.all_tokens.data_ptr(), self.all_n.data_ptr())
-                else:
-                    with torch.cuda.stream(self.stream):
-                        P.gather_tokens(self.tokens, self.n_tok, world, max_shard=B, group=self.group)
+        def _exchange(self, pass_id):
+            if world > 1:              # the path's only exchange, once per pass: handed to the rank's ONE exchange thread, which issues in pass order
+                self.pass_done = torch.cuda.Event()
+                self.pass_done.record(self.stream)
+                self.gather_done = torch.cuda.Event()
+                self.last_pass = pass_id
+                exch.submit(pass_id, self)
 
     R = max(1, min(args.replicas, args.steps))
     t0 = time.time()
@@ -462,33 +688,45 @@ def main():
     log(f"[bench] {R} replica(s) loaded in {time.time() - t0:.1f}s")
     ctx = reps[0].ctx
     dp_mode = "none"
+    exch = None
+    pass_counter = [0]
     if world > 1:
-        # one exchange channel per replica, so that the replicas' host threads never interleave collectives on a shared communicator
+        # ONE exchange channel per rank: its own stream + context + communicator; gathers issued by one thread in pass order (Exchanger)
+        xstream = torch.cuda.Stream()
+        xctx = m.Context(local_rank, stream=xstream.cuda_stream)
         use_abi = args.dp == "abi" and not rehearsal
-        ok = torch.ones(1, dtype=torch.int32, device="cuda" if not rehearsal else "cpu")
         if use_abi:
-            for rp in reps:
-                ids = [P.dp_unique_id(rp.ctx) if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                try:
-                    P.dp_init(rp.ctx, rank, world, ids[0])
-                    rp.dp_abi = True
-                except m.MiaError as e:
-                    log(f"[bench] rank {rank}: mia_dp_init failed ({e}); falling back to torch.distributed")
-                    ok[0] = 0
+            # mia_dp_init is a collective: vote on RCCL availability FIRST, so that a rank that cannot bind RCCL never leaves its peers
+            # blocked inside ncclCommInitRank
+            ok = torch.tensor([P.dp_available(xctx)], dtype=torch.int32, device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if not use_abi or int(ok.item()) == 0:
-            for rp in reps:
-                if rp.dp_abi:
-                    P.dp_shutdown(rp.ctx)
-                    rp.dp_abi = False
-                rp.group = dist.new_group(ranks=list(range(world)), backend="gloo" if rehearsal else "nccl")
-            dp_mode = "torch.distributed all_gather, one group per replica"
+            use_abi = int(ok.item()) == 1
+            if not use_abi:
+                log(f"[bench] rank {rank}: RCCL cannot be bound behind the C ABI on every rank; using torch.distributed for the gather")
+        if use_abi:
+            ids = [P.dp_unique_id(xctx) if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            P.dp_init(xctx, rank, world, ids[0])
+            dp_mode = "mia_dp_gather_tokens (RCCL behind the C ABI): one communicator on the rank's exchange stream, gathers issued in pass order by one thread"
         else:
-            dp_mode = "mia_dp_gather_tokens (RCCL behind the C ABI), one communicator per replica stream"
+            dp_mode = "torch.distributed all_gather on the rank's exchange stream, issued in pass order by one thread"
+
+        def issue(rp):
+            xstream.wait_event(rp.pass_done)
+            if use_abi:
+                P.dp_gather_tokens(xctx, rp.tokens.data_ptr(), rp.n_tok.data_ptr(), B, rp.opts.max_tokens, B * world, rp.all_tokens.data_ptr(), rp.all_n.data_ptr())
+            else:
+                with torch.cuda.stream(xstream):
+                    P.gather_tokens(rp.tokens, rp.n_tok, world, max_shard=B)
+            rp.gather_done.record(xstream)
+
+        exch = Exchanger(issue)
 
     def run_passes(k):
-        """k passes dealt round-robin over the replicas, one host thread per replica; returns when every stream has drained."""
+        """k passes dealt round-robin over the replicas (pass i -> replica i % R on EVERY rank), one host thread per replica; returns
+        when every stream has drained."""
+        base = pass_counter[0]
+        pass_counter[0] += k
         if args.schedule == "phased" and R > 1:
             # rounds of up to R passes: every replica's log-mel + encoder first (MFMA-bound: they may share the chip freely), then every
             # replica's decoder concurrently from its own host thread.  Decoders of different batches overlap each other well (three
@@ -503,7 +741,7 @@ def main():
                 for rp in act:
                     rp.ctx.synchronize()
                 tp1 = time.perf_counter()
-                ths = [threading.Thread(target=rp.step_decode) for rp in act]
+                ths = [threading.Thread(target=rp.step_decode, args=(base + (k - left) + i,)) for i, rp in enumerate(act)]
                 for t in ths:
                     t.start()
                 for t in ths:
@@ -514,17 +752,18 @@ def main():
                 if args.phase_log:
                     log(f"[bench] round of {len(act)}: encoders {1e3 * (tp1 - tp0):.1f} ms, decoders {1e3 * (time.perf_counter() - tp1):.1f} ms")
                 left -= len(act)
-            return
-        counts = [k // R + (1 if r < k % R else 0) for r in range(R)]
-        if R == 1:
-            for _ in range(counts[0]):
-                reps[0].step()
+        elif R == 1:
+            for i in range(k):
+                reps[0].step(base + i)
         else:
-            ths = [threading.Thread(target=lambda rp=rp, c=c: [rp.step() for _ in range(c)]) for rp, c in zip(reps, counts) if c]
+            ths = [threading.Thread(target=lambda rp=rp, r=r: [rp.step(base + i) for i in range(r, k, R)]) for r, rp in enumerate(reps) if r < k]
             for t in ths:
                 t.start()
             for t in ths:
                 t.join()
+        if exch is not None:
+            exch.wait_issued(base + k - 1)
+            xstream.synchronize()
         for rp in reps:
             rp.ctx.synchronize()
             rp.stream.synchronize()
@@ -548,8 +787,13 @@ def main():
         ctx.profile_reset()
         fence()
         ts = time.perf_counter()
-        for _ in range(n_serial):
-            reps[0].step()
+        base = pass_counter[0]
+        pass_counter[0] += n_serial
+        for i in range(n_serial):
+            reps[0].step(base + i)
+        if exch is not None:
+            exch.wait_issued(base + n_serial - 1)
+            xstream.synchronize()
         ctx.synchronize()
         reps[0].stream.synchronize()
         serial_s = time.perf_counter() - ts
@@ -652,8 +896,11 @@ def main():
     if rank == 0 and not args.no_codec:
         torch.cuda.set_stream(reps[0].stream)     # the codec leg times library work with torch events: same stream as the context
         out["codec"] = codec_bench(ctx, torch)
-    if rank == 0 and args.lm:
-        out["lm"] = lm_bench(ctx, torch, args.lm, args.lm_batch)
+    if rank == 0 and args.lm and not args.no_lm:
+        try:
+            out["lm"] = lm_bench(ctx, torch, args.lm, args.lm_batch)
+        except Exception as e:   # the side legs must never take the headline number down with them
+            out["lm"] = {"error": repr(e)}
     if rank == 0 and not args.no_config0 and not args.no_cpu_baseline:
         try:
             out["config0"] = config0_leg(ctx, torch)
@@ -666,13 +913,14 @@ def main():
         except Exception as e:  # the CPU leg must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "audio-sec/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
     if world > 1:
+        exch.close(pass_counter[0])
+        if use_abi:
+            P.dp_shutdown(xctx)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
     for rp in reversed(reps):                     # clones before the replica that owns the weights
-        if rp.dp_abi:
-            P.dp_shutdown(rp.ctx)
         rp.model.close()
 
 

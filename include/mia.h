@@ -66,6 +66,10 @@ int mia_synchronize(mia_ctx* ctx);
 int mia_profile_enable(mia_ctx* ctx, int on);
 int mia_profile_reset(mia_ctx* ctx);
 int mia_profile_read(mia_ctx* ctx, const char* kernel_class, int64_t* launches, double* total_ms, double* total_work);
+/* Algorithmic bytes of the fp32 codec / flow / vocoder launches (tap GEMMs, depthwise convs, embeds, noise blocks) issued by the CALLING
+ * HOST THREAD since the last reset: per launch each distinct input row once + each output element once + the weights once + residual
+ * inputs once (SURVEY.md 8(d)'s byte model for SNAC / DAC / HiFT).  reset != 0 clears the counter after reading. */
+double mia_profile_codec_bytes(int reset);
 
 /* ---- DSP front end -------------------------------------------------------------------------- */
 /* Whisper log-mel.  Replaces whisperLogMelSpectrogram(audio:nMels:padding:)
@@ -117,6 +121,7 @@ int mia_resample_sinc(mia_ctx* ctx, const float* x, int64_t n_samples, int from_
  * reference has no multi-device path (one actor, one Metal device: STT/Whisper/WhisperSTT.swift:11); these entry points are what
  * a Swift host driving 8 processes would bind.
  *   shard rule: contiguous shards, the first n_items % world ranks hold one item more (mia_dp_shard_range, host arithmetic);
+ *   mia_dp_available: 1 when RCCL can be bound in this process; mia_dp_init is a collective, so ranks vote on this first;
  *   mia_dp_unique_id: rank 0 makes the 128-byte RCCL id and hands it to the other ranks by its own means (pipe, file, env);
  *   mia_dp_init: collective over all ranks (ncclCommInitRank); one communicator per context; mia_dp_shutdown destroys it
  *     (mia_destroy does too);
@@ -126,6 +131,7 @@ int mia_resample_sinc(mia_ctx* ctx, const float* x, int64_t n_samples, int from_
 int mia_dp_shard_range(int n_items, int rank, int world, int* lo, int* hi);
 int mia_dp_shard_cap(int n_items, int world);
 int mia_dp_unpack_host(const int32_t* gathered, int n_items, int world, int L, int32_t* dense);
+int mia_dp_available(void);
 int mia_dp_unique_id(mia_ctx* ctx, void* id128);
 int mia_dp_init(mia_ctx* ctx, int rank, int world, const void* unique_id);
 int mia_dp_shutdown(mia_ctx* ctx);

@@ -42,6 +42,8 @@ struct EmbedArgs {
 };
 
 const char* codec_conv_gemm_check(const ConvGemmArgs& g);
+// algorithmic bytes of the fp32 conv / elementwise launches issued by the calling host thread since the last reset (profiling aid)
+double codec_alg_bytes(bool reset);
 int codec_conv_gemm_launch(const ConvGemmArgs& g, int phases, hipStream_t s);
 int codec_dwconv_launch(const float* x, float* y, const float* w, const float* bias, const float* a_pre, const float* a_post, int T, int C,
                         int K, int dil, hipStream_t s);

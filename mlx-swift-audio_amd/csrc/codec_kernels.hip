@@ -420,7 +420,28 @@ const char* codec_conv_gemm_check(const ConvGemmArgs& g) {
   return nullptr;
 }
 
+// ---- algorithmic-byte accounting (profiling aid behind mia_profile_codec_bytes; SURVEY.md 8(d): "SNAC / DAC / HiFT decode: HBM-bound,
+// report bytes as the sum over fused ops of one read + one write of the activation tensor").  Every launcher below adds what its launch
+// must move at minimum -- each distinct input row once, each output element once, the weights once, residual inputs once -- to a
+// counter of the calling host thread.
+static thread_local double t_alg_bytes = 0.0;
+double codec_alg_bytes(bool reset) { const double v = t_alg_bytes; if (reset) t_alg_bytes = 0.0; return v; }
+
+static void account_conv_gemm(const ConvGemmArgs& g, int phases) {
+  const bool stacked = g.x_phase_step != 0;                          // grid.z = stacked sequences (own X rows); else = stride phases of ONE input
+  const double rows_in = std::min<double>((double)g.T_in, (double)g.M * g.x_row_mul + (double)g.taps * g.dil);
+  double b = rows_in * g.Cin * 4.0 * (stacked ? phases : 1);
+  b += (double)g.N * g.taps * g.Cin * 4.0 * (g.w_phase_stride ? phases : 1);
+  const double out = (double)g.M * g.N * 4.0 * phases;
+  b += out;
+  if (g.R) b += out;
+  if (g.R2) b += out;
+  if (g.noise) b += (double)g.M * 4.0 * phases;
+  t_alg_bytes += b;
+}
+
 int codec_conv_gemm_launch(const ConvGemmArgs& g, int phases, hipStream_t s) {
+  account_conv_gemm(g, phases);
   // 128-row tiles only when they still give every CU work; otherwise 64 x 64 tiles (4x the workgroups)
   const int64_t big_blocks = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * phases;
   if (big_blocks < 384) {
@@ -441,6 +462,7 @@ int codec_conv_gemm_launch(const ConvGemmArgs& g, int phases, hipStream_t s) {
 int codec_dwconv_launch(const float* x, float* y, const float* w, const float* bias, const float* a_pre, const float* a_post, int T, int C,
                         int K, int dil, hipStream_t s) {
   if (C % 4) return -1;
+  t_alg_bytes += 2.0 * T * C * 4.0 + (double)K * C * 4.0;
   const int64_t total = (int64_t)T * (C / 4);
   const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(dwconv_snake, dim3(grid), dim3(256), 0, s, x, y, w, bias, a_pre, a_post, T, C, K, dil);
@@ -449,6 +471,7 @@ int codec_dwconv_launch(const float* x, float* y, const float* w, const float* b
 
 int codec_conv_out1_launch(const float* x, float* out, const float* w, const float* bias, const float* alpha, int T, int C, int K, hipStream_t s) {
   if (C % 4) return -1;
+  t_alg_bytes += (double)T * C * 4.0 + (double)T * 4.0;
   const size_t lds = (size_t)(K * C + 2 * C) * 4;
   hipLaunchKernelGGL(conv_out1, dim3((T + 255) / 256), dim3(256), lds, s, x, out, w, bias, alpha, T, C, K);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -456,12 +479,14 @@ int codec_conv_out1_launch(const float* x, float* out, const float* w, const flo
 
 int codec_embed_launch(const EmbedArgs& a, float* z, int T, int C, hipStream_t s) {
   const int64_t total = (int64_t)T * C;
+  t_alg_bytes += (double)total * 4.0;
   const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(embed_codes, dim3(grid), dim3(256), 0, s, a, z, T, C);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int codec_noise1_launch(float* x, const float* w, const float* noise, int T, int C, hipStream_t s) {
+  t_alg_bytes += 2.0 * T * C * 4.0 + (double)T * 4.0;
   hipLaunchKernelGGL(noise_mod1, dim3((T + 3) / 4), dim3(256), 0, s, x, w, noise, T, C);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "mia_internal.h"
 
@@ -30,22 +31,24 @@ struct RcclApi {
   std::string err;
 };
 
-RcclApi& rccl() {
-  static RcclApi api;
-  static bool tried = false;
-  if (tried) return api;
-  tried = true;
+void rccl_bind(RcclApi& api) {
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     if (api.lib) break;
   }
-  if (!api.lib) { api.err = std::string("dlopen(librccl) failed: ") + (dlerror() ? dlerror() : "?"); return api; }
+  if (!api.lib) { api.err = std::string("dlopen(librccl) failed: ") + (dlerror() ? dlerror() : "?"); return; }
   api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
   api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
   api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
   api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
   if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) { api.err = "librccl lacks the nccl* entry points"; api.lib = nullptr; }
+}
+
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] { rccl_bind(api); });
   return api;
 }
 
@@ -93,6 +96,11 @@ extern "C" int mia_dp_unpack_host(const int32_t* gathered, int n_items, int worl
 }
 
 // ---- RCCL ---------------------------------------------------------------------------------------------------------------------------------
+// 1 when RCCL can be bound in this process (dlopen + the four entry points), else 0.  mia_dp_init is a COLLECTIVE: a rank whose
+// binding fails would leave its peers blocked inside ncclCommInitRank, so callers vote on this (e.g. an all-reduce MIN over their
+// bootstrap channel) before any rank calls mia_dp_init.
+extern "C" int mia_dp_available(void) { return rccl().lib ? 1 : 0; }
+
 extern "C" int mia_dp_unique_id(mia_ctx* ctx, void* id128) {
   if (!ctx || !id128) return MIA_ERR_INVALID_ARGUMENT;
   RcclApi& a = rccl();
@@ -150,7 +158,10 @@ extern "C" int mia_dp_gather_tokens(mia_ctx* ctx, const int32_t* local_tokens, c
   // staging: [send: cap rows of (L + 1) ints: tokens | count] [recv: world * cap rows] [plan: 3 * world ints]
   const int W = L + 1;
   const size_t send_b = (size_t)cap * W * 4, recv_b = send_b * world, plan_b = (size_t)3 * world * 4;
-  const size_t need = align_up(send_b, 256) + align_up(recv_b, 256) + align_up(recv_b, 256) + plan_b;
+  // the unpadding plan sits at a FIXED offset (the start of the buffer): its address must not move with L, because it is uploaded
+  // only when (n_items, world) change
+  const size_t plan_off = align_up(plan_b, 256);
+  const size_t need = plan_off + align_up(send_b, 256) + align_up(recv_b, 256) + align_up(recv_b, 256);
   if (ctx->dp_buf_bytes < need) {
     MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->dp_buf) (void)hipFree(ctx->dp_buf);
@@ -160,10 +171,10 @@ extern "C" int mia_dp_gather_tokens(mia_ctx* ctx, const int32_t* local_tokens, c
     ctx->dp_plan_items = -1;
   }
   char* base = (char*)ctx->dp_buf;
-  int32_t* send = (int32_t*)base;
-  int32_t* recv = (int32_t*)(base + align_up(send_b, 256));
-  int32_t* dense = (int32_t*)(base + align_up(send_b, 256) + align_up(recv_b, 256));
-  int32_t* plan = (int32_t*)(base + align_up(send_b, 256) + 2 * align_up(recv_b, 256));
+  int32_t* plan = (int32_t*)base;
+  int32_t* send = (int32_t*)(base + plan_off);
+  int32_t* recv = (int32_t*)(base + plan_off + align_up(send_b, 256));
+  int32_t* dense = (int32_t*)(base + plan_off + align_up(send_b, 256) + align_up(recv_b, 256));
   hipStream_t s = ctx->stream;
   // one message per rank: rows of [tokens(L) | count], padded with zero rows up to cap
   MIA_HIP(ctx, hipMemsetAsync(send, 0, send_b, s));

@@ -19,6 +19,7 @@
 #include "mia_internal.h"
 
 #include <cmath>
+#include <mutex>
 
 namespace {
 
@@ -238,10 +239,14 @@ int get_tables(mia_ctx* ctx, int n_mels, int window_kind, mia_ctx::MelTables** o
   MIA_HIP(ctx, hipMalloc(&t.twiddle, tw.size() * sizeof(float)));
   MIA_HIP(ctx, hipMalloc(&t.fb_w, w.size() * sizeof(float)));
   MIA_HIP(ctx, hipMalloc(&t.fb_meta, meta.size() * sizeof(int)));
-  MIA_HIP(ctx, hipMemcpy(t.window, win.data(), NFFT * sizeof(float), hipMemcpyHostToDevice));
-  MIA_HIP(ctx, hipMemcpy(t.twiddle, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
-  MIA_HIP(ctx, hipMemcpy(t.fb_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
-  MIA_HIP(ctx, hipMemcpy(t.fb_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+  // uploads go through the context's OWN stream: a synchronous hipMemcpy runs on the legacy stream, which is illegal while another host
+  // thread captures a step graph on a blocking stream (bench.py's replicas; seen as "operation would make the legacy stream depend on a
+  // capturing blocking stream" in a 2-rank rehearsal)
+  MIA_HIP(ctx, hipMemcpyAsync(t.window, win.data(), NFFT * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MIA_HIP(ctx, hipMemcpyAsync(t.twiddle, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MIA_HIP(ctx, hipMemcpyAsync(t.fb_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MIA_HIP(ctx, hipMemcpyAsync(t.fb_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->mel_tables.push_back(t);
   *out = &ctx->mel_tables.back();
   return MIA_OK;
@@ -298,11 +303,11 @@ int mia_logmel_device(mia_ctx* ctx, const float* pcm_dev, const int64_t* offs_ho
   const int prof_rec = mia_prof_begin(ctx, MIA_PROF_LOGMEL, alg_bytes);
   hipLaunchKernelGGL(logmel_init, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, d_gmax, B);
   if (max_content > 0) {
-    static bool lds_attr_set = false;   // 86 KB of dynamic LDS: above the 64 KB default cap
-    if (!lds_attr_set) {
-      MIA_HIP(ctx, hipFuncSetAttribute((const void*)logmel_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS1_LDS));
-      lds_attr_set = true;
-    }
+    // 86 KB of dynamic LDS: above the 64 KB default cap.  Several contexts (bench.py's replica threads) reach this concurrently.
+    static std::once_flag lds_attr_once;
+    static hipError_t lds_attr_rc = hipSuccess;
+    std::call_once(lds_attr_once, [] { lds_attr_rc = hipFuncSetAttribute((const void*)logmel_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS1_LDS); });
+    MIA_HIP(ctx, lds_attr_rc);
     dim3 grid((unsigned)((max_content + FB - 1) / FB), (unsigned)B);
     hipLaunchKernelGGL(logmel_pass1, grid, dim3(256), PASS1_LDS, ctx->stream, pcm_dev, d_clips, pad_right, n_out, n_mels,
                        tb->window, tb->twiddle, tb->fb_w, tb->fb_meta, tb->fb_nnz, d_tmp, d_gmax);

@@ -96,7 +96,8 @@ int get_tables(mia_ctx* ctx, S3GenMelTables** out) {
   const size_t bytes[3] = {dft.size() * 4, w.size() * 4, meta.size() * 4};
   const void* src[3] = {dft.data(), w.data(), meta.data()};
   for (int i = 0; i < 3; ++i) {
-    if (hipMalloc(&p[i], bytes[i] + 64) != hipSuccess || hipMemcpy(p[i], src[i], bytes[i], hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMalloc(&p[i], bytes[i] + 64) != hipSuccess || hipMemcpyAsync(p[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {     // the context's own stream, never the legacy stream (see logmel.hip)
       for (int j = 0; j <= i; ++j) if (p[j]) (void)hipFree(p[j]);
       free(t);
       return mia_fail(ctx, MIA_ERR_OUT_OF_MEMORY, "mel_s3gen: table upload failed");

@@ -1,5 +1,6 @@
 // mia_ctx.hip -- context lifecycle for the C ABI (include/mia.h).
 #include <cstdlib>
+#include "codec.h"
 #include "mia_internal.h"
 
 extern "C" const char* mia_version(void) { return "mia 0.1 (gfx950)"; }
@@ -113,6 +114,8 @@ extern "C" int mia_profile_enable(mia_ctx* ctx, int on) {
   ctx->prof_on = on != 0;
   return MIA_OK;
 }
+
+extern "C" double mia_profile_codec_bytes(int reset) { return codec_alg_bytes(reset != 0); }
 
 extern "C" int mia_profile_reset(mia_ctx* ctx) {
   if (!ctx) return MIA_ERR_INVALID_ARGUMENT;

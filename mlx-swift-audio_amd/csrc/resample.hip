@@ -105,7 +105,8 @@ extern "C" int mia_resample_sinc(mia_ctx* ctx, const float* x, int64_t n_samples
     float* dev = nullptr;
     MIA_HIP(ctx, hipMalloc((void**)&dev, host.size() * 4));
     ctx->table_allocs.push_back(dev);
-    MIA_HIP(ctx, hipMemcpy(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    MIA_HIP(ctx, hipMemcpyAsync(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice, s));   // own stream, never the legacy stream (see logmel.hip)
+    MIA_HIP(ctx, hipStreamSynchronize(s));
     const int g = std::gcd(from_rate, to_rate);
     ctx->resampler->tables.push_back(SincTable{from_rate, to_rate, to_rate / g, from_rate / g, taps, (taps - 1) / 2, dev});
     tb = &ctx->resampler->tables.back();

@@ -10,6 +10,7 @@
 //   attention: fp32, LDS-tiled (32 queries x 64-key tiles), exact softmax
 //   FSQ: round(tanh(W x + b) * 0.999) + 1 in base 3 (rintf = half-to-even like MLX round)
 #include <cmath>
+#include <mutex>
 #include <map>
 #include <string>
 #include <vector>
@@ -296,8 +297,8 @@ static int s3_encode_clip(mia_s3tok* m, const float* d_mel, int64_t ld_mel, int 
   const float scale = powf(64.0f, -0.25f);
   const size_t att_lds = (size_t)(32 * (((T2 + 63) & ~63) + 1) + 32 * 65 + 64 * 65) * 4;
   if (att_lds > 160 * 1024) return mia_fail(ctx, MIA_ERR_UNSUPPORTED, "s3tok: window too long for the attention kernel (%d tokens)", T2);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)s3_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] { (void)hipFuncSetAttribute((const void*)s3_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   for (const S3Block& b : m->blocks) {
     if (mia_norm_launch(x, D, b.attn_ln_g, b.attn_ln_b, h, D, T2, D, 1e-5f, false, MIA_F32, s)) return mia_fail(ctx, MIA_ERR_DEVICE, "s3tok: norm launch failed");
     { ConvGemmArgs g; g.X = h; g.ldx = D; g.T_in = T2; g.W = b.wqkv; g.bias = b.bqkv; g.M = T2; g.N = 3 * D; g.Cin = D; g.Y = qkv; g.ldy = 3 * D; g.T_out = T2;

@@ -42,6 +42,14 @@ def gather_tokens(local_tokens, local_counts, world: int, max_shard: int | None 
 
 
 # ---- the same exchange through the C ABI (include/mia.h "data-parallel exchange"): RCCL on the context's own stream ----------------
+def dp_available(ctx) -> int:
+    """1 when RCCL can be bound in this process (mia_dp_available).  mia_dp_init is a collective: vote on this across ranks first."""
+    import ctypes as C
+    ctx.lib.mia_dp_available.restype = C.c_int
+    ctx.lib.mia_dp_available.argtypes = []
+    return int(ctx.lib.mia_dp_available())
+
+
 def dp_unique_id(ctx) -> bytes:
     """Rank 0: the 128-byte RCCL id to hand to every other rank (mia_dp_unique_id)."""
     import ctypes as C

@@ -111,6 +111,41 @@ def test_whisper_turbo_headline_batch_32(ctx, turbo):
         np.testing.assert_array_equal(fs, feats[i:i + 4])
 
 
+def test_whisper_turbo_f16_ids_bit_exact(ctx):
+    """large-v3-turbo at full size in f16 parity mode (the reference's storage type, WhisperSTT.swift:157,182) on a NON-degenerate
+    checkpoint (style 'peaky', seed 18: picked offline with the CPU oracle among 50 seeds): the oracle's run of 2 clips x 64 tokens
+    has >= 16 distinct ids per clip, finite avg_logprob, different ids per clip, and a smallest top-2 margin >= 10 x the logit noise
+    measured here; HIP must emit exactly the oracle's ids -- whole run, end to end (log-mel, 32-layer encoder, decoder), no fork rule."""
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import whisper as HW
+    from oracle import logmel as OL
+    from oracle import whisper as OW
+    from _whisper_trace import check_clip, first_fork, nondegenerate
+    dims = S.DIMS["large-v3-turbo"]
+    weights = S.synthetic_weights(dims, seed=18, style="peaky", round_to="f16")
+    model = HW.WhisperModel.load(ctx, dims, weights, m.F16)
+    n_new = 64
+    sup = S.synthetic_suppress_list(model.special)
+    kw = dict(suppress_ids=sup, blank_ids=[220], max_new_tokens=n_new)
+    clips = [S.synth_clip(5), S.synth_clip(30)]
+    model.trace_logits([0, 1])
+    got = model.transcribe_windows(clips, HW.DecodingOptions(**kw))
+    ora = OW.WhisperOracle(dims, weights)
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    mel = np.stack([OW.round_array(OL.whisper_log_mel_spectrogram(c, dims.n_mels, padding=OL.N_SAMPLES)[:OL.N_FRAMES], "f16") for c in clips])
+    xa = ora.encode(mel)
+    oo = OW.DecodingOptions(**kw)
+    refs = [OW.greedy_decode(ora, st, xa[b:b + 1], oo) for b in range(2)]
+    min_margin = nondegenerate(refs, n_new)
+    noise = 0.0
+    for b in range(2):
+        assert got[b].tokens == refs[b].tokens, (b, first_fork(got[b].tokens, refs[b].tokens), refs[b].margins)
+        assert abs(got[b].avg_logprob - refs[b].avg_logprob) <= 5e-3
+        noise = max(noise, check_clip(model, ora, st, oo, got[b], b, xa[b:b + 1], "f16", n_new, tol_scale=2.0)["noise_rms"])   # 32 encoder layers deep
+    assert min_margin >= 10 * noise, (min_margin, noise)
+    model.close()
+
+
 def test_qwen2_half_billion_full_size(ctx):
     import mlx_swift_audio_amd as m
     from mlx_swift_audio_amd import lm as HL

@@ -106,6 +106,99 @@ def test_abi_shard_and_unpack_match_python_rule():
     assert lib.mia_dp_shard_cap(4, 0) < 0
 
 
+def test_bench_self_launch_dry_run_world2():
+    """`python bench.py --gpus 2 --dry-run` without a launcher: bench.py becomes the launcher (child processes, sysfs device count, no
+    HIP), both ranks run 3 replica threads whose 'decodes' finish in jittered order, the rank's ONE exchange thread issues the gathers
+    in pass order over gloo, every rank verifies every gathered row, rank 0 prints the contract line with n_gpus 2; every rank must
+    exit 0 (the launcher returns the worst exit code)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "7", "--warmup", "1", "--batch", "4",
+                        "--replicas", "3"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["exchange_order_ok"] is True and d["config"]["passes_exchanged"] == 10 and d["config"]["replicas"] == 3
+    # a failing rank must surface: WORLD_SIZE that contradicts --gpus makes every child exit non-zero
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="3", RANK="0"))
+    assert bad.returncode != 0
+
+
+def test_exchanger_issues_in_pass_order():
+    """bench.py's Exchanger: submissions arrive out of order from several threads, issue order is 0, 1, 2, ...; an error inside one issue
+    does not strand the submitters and is re-raised by close()."""
+    import importlib.util
+    import random
+    import threading
+    import time
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = []
+    ex = bench.Exchanger(lambda p: seen.append(p))
+    ids = list(range(40))
+    random.Random(3).shuffle(ids)
+
+    def feed(chunk):
+        for i in chunk:
+            time.sleep(0.001 * (i % 3))
+            ex.submit(i, i)
+    ths = [threading.Thread(target=feed, args=(ids[k::4],)) for k in range(4)]
+    for t in ths:
+        t.start()
+    ex.wait_issued(39)
+    for t in ths:
+        t.join()
+    ex.close(40)
+    assert seen == list(range(40)) and ex.order == list(range(40))
+
+    def boom(p):
+        if p == 2:
+            raise RuntimeError("gather failed")
+    ex2 = bench.Exchanger(boom)
+    for i in range(4):
+        ex2.submit(i, i)
+    ex2.wait_issued(3)
+    with pytest.raises(RuntimeError):
+        ex2.close(4)
+
+
+def test_visible_gpu_count_needs_no_runtime():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench.visible_gpu_count()
+    assert isinstance(n, int) and n >= 0
+    os.environ["HIP_VISIBLE_DEVICES"] = ""
+    try:
+        assert bench.visible_gpu_count() == 0
+    finally:
+        del os.environ["HIP_VISIBLE_DEVICES"]
+
+
+@pytest.mark.gpu
+def test_abi_rccl_gather_two_row_lengths(ctx):
+    """the unpadding plan is cached under (n_items, world) while the staging layout depends on L -- a second call with another L
+    on the same context must still compact correctly (the plan now sits at a fixed offset of the staging buffer)."""
+    from mlx_swift_audio_amd import parallel as P
+    P.dp_init(ctx, 0, 1, P.dp_unique_id(ctx))
+    assert P.dp_available(ctx) == 1
+    for L in (448, 16, 448, 7):                        # shrink (no regrow), grow back, shrink again
+        toks, counts = _fake_tokens(0, 5, L)
+        t_d, c_d = toks.cuda(), counts.cuda()
+        out_t, out_c = torch.zeros_like(t_d), torch.zeros_like(c_d)
+        P.dp_gather_tokens(ctx, t_d.data_ptr(), c_d.data_ptr(), 5, L, 5, out_t.data_ptr(), out_c.data_ptr())
+        ctx.synchronize()
+        assert torch.equal(out_t.cpu(), toks) and torch.equal(out_c.cpu(), counts), L
+    P.dp_shutdown(ctx)
+
+
 @pytest.mark.gpu
 def test_abi_rccl_gather_world_1(ctx):
     """mia_dp_* on the real RCCL (one rank: communicator set-up, the all-gather on the context's stream, unpadding, shutdown)."""
