@@ -359,12 +359,15 @@ typedef struct {
 } mia_lm_sampler;
 
 mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia_tensor_view* tensors, int n_tensors, int dtype);
-/* MLX-affine 4-bit (group 64) weights for the decode step: the reference's default Orpheus / CosyVoice2 checkpoints are quantised
- * (TTS/Orpheus/TTSEngine/OrpheusWeightLoader.swift:28-60) and MLX multiplies them packed (quantizedMatmul).  mia_lm_attach_q4 takes
- * every step Linear as stored -- `<name>.weight` (MIA_U32 codes [N][K/8], 8 per word, little end first), `<name>.scales`, `<name>.biases`
- * ([N][K/64], both f16 or both bf16) -- onto a handle loaded from the de-quantised checkpoint; the per-token step then streams 4.5 bits
- * per weight and expands them in registers to exactly the 16-bit values of the expanded checkpoint (identical logits), the batched
- * prompt pass keeps the 16-bit copy.  mia_lm_use_q4 toggles the step between the two (0 = 16-bit). */
+/* MLX-affine quantised (group 64; 4- or 8-bit codes) weights for the decode step: the reference's default Orpheus / CosyVoice2
+ * checkpoints are quantised (TTS/Orpheus/TTSEngine/OrpheusWeightLoader.swift:28-60; the bit width is a loader option,
+ * Models/TranscriptionResult.swift:162-198) and MLX multiplies them packed (quantizedMatmul).  mia_lm_attach_quantized takes every step
+ * Linear as stored -- `<name>.weight` (MIA_U32 codes [N][K * bits / 32], little end first), `<name>.scales`, `<name>.biases` ([N][K/64],
+ * both f16 or both bf16) -- onto a handle loaded from the de-quantised checkpoint; the per-token step then streams the packed codes and
+ * multiplies them as MLX's own kernels do (per group: scale * sum(code * x) + bias * sum(x), the codes exact in the MFMA's 16-bit
+ * operands, fp32 group sums), the batched prompt pass keeps the 16-bit copy.  One attach per handle.  mia_lm_attach_q4 = bits 4.
+ * mia_lm_use_q4 toggles the step between the packed and the 16-bit weights (0 = 16-bit). */
+int mia_lm_attach_quantized(mia_lm* lm, const mia_tensor_view* tensors, int n_tensors, int group_size, int bits);
 int mia_lm_attach_q4(mia_lm* lm, const mia_tensor_view* tensors, int n_tensors, int group_size);
 int mia_lm_use_q4(mia_lm* lm, int on);
 /* Test hook: bit 0 = launch every step's kernels directly (no hipGraph), bit 1 = feed prompts token by token (no batched prompt

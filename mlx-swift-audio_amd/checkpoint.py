@@ -122,10 +122,12 @@ def load_whisper_checkpoint(ctx: _lib.Context, model_dir: str):
 
 
 def quantize_affine(w: np.ndarray, group_size: int = 64, bits: int = 4, scale_dtype=np.float16):
-    """MLX affine quantisation of one weight matrix, the direction the reference's loaders take for checkpoints that are not already
-    quantised (`quantize(model:) { (64, bits, .affine) }`, STT/Whisper/WhisperModel.swift:189-196): per group of `group_size`
-    consecutive inputs, scale = (max - min) / (2^bits - 1), bias = min, code = round((w - bias) / scale); codes packed little end
-    first into uint32 words.  Returns (codes uint32 [N, K*bits/32], scales, biases [N, K/group_size] in `scale_dtype`) -- the three
+    """A SIMPLIFIED min / max affine quantiser in MLX's storage layout -- the direction the reference's loaders take for checkpoints
+    that are not already quantised (`quantize(model:) { (64, bits, .affine) }`, STT/Whisper/WhisperModel.swift:189-196): per group of
+    `group_size` consecutive inputs, scale = (max - min) / (2^bits - 1), bias = min, code = round((w - bias) / scale); codes packed
+    little end first into uint32 words.  mx.quantize additionally nudges scale / bias (edge and sign handling), which this does not
+    reproduce: parity of the CODES with mx.quantize is unpinned; the contract of the hot path is de-quantisation (scale * code + bias),
+    which is layout-exact.  Returns (codes uint32 [N, K*bits/32], scales, biases [N, K/group_size] in `scale_dtype`) -- the three
     tensors a quantised checkpoint stores for the layer (feed them to CausalLM.attach_q4 / expand them with dequantize_affine)."""
     w = np.asarray(w, np.float32)
     n, k = w.shape

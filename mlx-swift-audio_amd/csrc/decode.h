@@ -38,8 +38,8 @@ int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t
 int dec_launch_repack_wfrag(const void* src, void* dst, int N, int K, hipStream_t s);
 // model-independent form (dtype = MIA_BF16 | MIA_F16); SK_SWIGLU: W rows interleaved gate/up, out[m][n/2] = silu(g)*u (16-bit)
 int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s);
-// MLX-affine 4-bit weights in fragment order (decode_kernels.hip: skinny_gemm_q4); modes SK_OUT16 / SK_OUTF32 / SK_PARTIAL / SK_SWIGLU
-int skinny_gemm_q4_launch(const SkinnyArgs& a, const uint32_t* wfrag, const uint16_t* sbfrag, int scale_dtype, int mode, int dtype, hipStream_t s);
+// MLX-affine 4- / 8-bit weights in fragment order (decode_kernels.hip: skinny_gemm_qi); modes SK_OUT16 / SK_OUTF32 / SK_PARTIAL / SK_SWIGLU
+int skinny_gemm_q_launch(const SkinnyArgs& a, const uint32_t* wfrag, const float* stfrag, int bits, int mode, int dtype, hipStream_t s);
 // qk_out (optional): pre-softmax scores of the heads with head_slot[h] >= 0 -> qk_out[b][slot][pos[b]][key] (word-timestamp alignment)
 int dec_launch_attention(mia_whisper* w, const void* q, const void* kc, const void* vc, void* out, int fixed_keys, int cap_keys,
                          hipStream_t s, float* qk_out = nullptr, const int32_t* head_slot = nullptr, int n_slots = 0, int qk_ctx = 0);

@@ -353,6 +353,14 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
   int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
   const uint16_t* ap0 = a.A + (int64_t)am0 * a.lda + kbeg + 8 * c;
   const uint16_t* ap1 = a.A + (int64_t)am1 * a.lda + kbeg + 8 * c;
+  // Only the lanes whose row exists fetch activations (the others feed zeros: their accumulator columns are never stored).  At one
+  // sequence that is 4 of 64 lanes in the first MFMA half and none in the second: a 16-byte wave load costs the address unit per
+  // ACTIVE lane, and with every lane fetching (rows clamped to the last one) the activation fragments were two of the three load
+  // instructions of every K-step.
+  const bool av0 = m0 + r < a.M, av1 = m0 + 16 + r < a.M;
+  const s16x8 zfrag = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  auto lda0 = [&](const uint16_t* p) -> s16x8 { s16x8 v = zfrag; if (av0) v = *reinterpret_cast<const s16x8*>(p); return v; };
+  auto lda1 = [&](const uint16_t* p) -> s16x8 { s16x8 v = zfrag; if (av1) v = *reinterpret_cast<const s16x8*>(p); return v; };
   f32x4 acc[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -364,8 +372,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
     for (int u = 0; u < KB; ++u) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) t.w[u][n] = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)((k >> 5) + u) * ws);
-      t.a0[u] = *reinterpret_cast<const s16x8*>(ap0 + k + 32 * u);
-      t.a1[u] = *reinterpret_cast<const s16x8*>(ap1 + k + 32 * u);
+      t.a0[u] = lda0(ap0 + k + 32 * u);
+      t.a1[u] = lda1(ap1 + k + 32 * u);
     }
   };
   auto mma_batch = [&](const Batch& t) {
@@ -393,8 +401,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
       if (u < rem) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) b3.w[u][n] = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)((ktail >> 5) + u) * ws);
-        b3.a0[u] = *reinterpret_cast<const s16x8*>(ap0 + ktail + 32 * u);
-        b3.a1[u] = *reinterpret_cast<const s16x8*>(ap1 + ktail + 32 * u);
+        b3.a0[u] = lda0(ap0 + ktail + 32 * u);
+        b3.a1[u] = lda1(ap1 + ktail + 32 * u);
       }
   }
   if (nb > 0) {
@@ -429,8 +437,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
       }
   } else {
     for (int k = ktail; k < Kc; k += 32) {
-      const s16x8 fa0 = *reinterpret_cast<const s16x8*>(ap0 + k);
-      const s16x8 fa1 = *reinterpret_cast<const s16x8*>(ap1 + k);
+      const s16x8 fa0 = lda0(ap0 + k);
+      const s16x8 fa1 = lda1(ap1 + k);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const s16x8 fw = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)(k >> 5) * ws);
@@ -474,13 +482,16 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
   int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
   const uint16_t* ap0 = a.A + (int64_t)am0 * a.lda + kbeg + 8 * c;
   const uint16_t* ap1 = a.A + (int64_t)am1 * a.lda + kbeg + 8 * c;
+  const bool av0 = m0 + r < a.M, av1 = m0 + 16 + r < a.M;     // only lanes whose row exists fetch activations (see dec_skinny_gemm)
+  const s16x8 zfrag = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
   s16x8 fw[NSTEP][NT], fa0[NSTEP], fa1[NSTEP];
 #pragma unroll
   for (int u = 0; u < NSTEP; ++u) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) fw[u][n] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp[n] + (int64_t)u * ws));
-    fa0[u] = *reinterpret_cast<const s16x8*>(ap0 + 32 * u);
-    fa1[u] = *reinterpret_cast<const s16x8*>(ap1 + 32 * u);
+    fa0[u] = zfrag; fa1[u] = zfrag;
+    if (av0) fa0[u] = *reinterpret_cast<const s16x8*>(ap0 + 32 * u);
+    if (av1) fa1[u] = *reinterpret_cast<const s16x8*>(ap1 + 32 * u);
   }
   __builtin_amdgcn_sched_barrier(0);   // keep every load ahead of the first MFMA (the scheduler would otherwise trade them for registers)
   f32x4 acc[NT][2];
@@ -643,23 +654,71 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same skinny GEMM on MLX-affine 4-bit weights (group 64: w = scale * code + bias), de-quantised IN REGISTERS: the step streams
-// 4.5 bits per weight from HBM instead of 16 (Orpheus-3B: 1.9 GB instead of 6.6 GB per token).  Replaces MLX's quantizedMatmul on the
-// reference's default checkpoints (TTS/Orpheus/TTSEngine/OrpheusWeightLoader.swift:28-60, STT/Whisper/WhisperModel.swift:189-200).
+// The same skinny GEMM on MLX-affine quantised weights (group 64: w = scale * code + bias; 4- or 8-bit codes), multiplied PACKED: the
+// step streams ~5 (or ~9) bits per weight from HBM instead of 16.  Replaces MLX's quantizedMatmul on the reference's default
+// checkpoints (TTS/Orpheus/TTSEngine/OrpheusWeightLoader.swift:28-60, STT/Whisper/WhisperModel.swift:189-200; 4- and 8-bit:
+// Models/TranscriptionResult.swift:162-198).
 //
-// HBM layout (built once at load, lm.hip): the packed words are stored in MFMA FRAGMENT order --
-//   wfrag [tile = n/16][blk = k/128][lane = 16 c + r][4 words]: word s of lane (r, c) = codes of W[16 tile + r][128 blk + 32 s + 8 c .. +7]
-//   (K-step s of the block, exactly the 8 inputs the lane feeds to v_mfma_f32_16x16x32), so a wave reads one coalesced 1 KB line per
-//   16 rows x 128 inputs and the K order of every accumulation is the dense kernel's;
-//   sbfrag [tile][blk][r][4] 16-bit: (scale, bias) of the block's two 64-input groups for row 16 tile + r (steps 0,1 / 2,3).
-// Each value is expanded as RNE_16bit(fmaf(scale, code, bias)) -- bit for bit the tensor mia_dequant_affine + the dense loader produce --
-// so logits are IDENTICAL to the expanded-checkpoint path (asserted in tests/test_lm_gpu.py), whatever the split.
+// Arithmetic (the one MLX's own qmv / qmm kernels use: scale * sum(code * x) + bias * sum(x) per group): the MFMA runs on the integer
+// CODES, which are exact in 16-bit floating point, and scale / bias are applied once per 64-input group to the group's partial sums:
+//     y[m][n] = sum_g ( s[n][g] * sum_{k in g} code[n][k] a[m][k]  +  b[n][g] * sum_{k in g} a[m][k] )
+// -- no per-weight de-quantisation at all.  A 4-bit code becomes a 16-bit float by OR-ing it into the mantissa of a magic constant
+// (bf16 0x4300 | q = 128 + q, f16 0x6400 | q = 1024 + q): with the nibbles stored so that (word >> 4 i) & 0x000f000f isolates the
+// codes of K-values 2 i and 2 i + 1, a lane's 8 MFMA operand values cost 7 VALU instructions (the first form of this kernel expanded
+// fmaf(scale, code, bias) and re-rounded per weight: 28 to 32 instructions per MFMA, and at one wave per SIMD the kernel ran at the VALU
+// issue latency -- 14 us for the 27 MB gate|up matrix of Orpheus-3B, 1.9 TB/s).  The magic offset is removed in the group fix-up:
+// sum (MAG + q) a = MAG A + sum q a, so y += s P + t A with t = b - MAG s (fp32, built at attach time) and A = sum_k a[m][k] -- itself
+// an MFMA with an all-ones operand, shared by the tiles of a wave.  An 8-bit code is two 4-bit planes, q = 16 hi + lo: the hi plane goes
+// through the same unpack + MFMA into its own accumulator, P = P_lo + 16 P_hi and t = b - 17 MAG s.
+//
+// HBM layout (built once at attach, lm.hip:q_repack):
+//   wfrag  [tile = n/16][blk = k/128][plane][lane = 16 c + r][4 words]: word st of lane (r, c) = the plane's nibbles of
+//          W[16 tile + r][128 blk + 32 st + 8 c .. +7], nibble of K-value 2 i at bits [4 i, 4 i + 4), of 2 i + 1 at bits [16 + 4 i, ..)
+//   stfrag [tile][blk][row r][4] fp32: (s, t) of the block's two groups -- the weights are the MFMA's COLUMN operand, so a lane's four
+//          accumulator values share one output column and one 16-byte load per block brings its scale and offset
+// Results agree with the 16-bit step on the de-quantised checkpoint to the rounding of the de-quantised weights to 16 bit (this form
+// does not round them at all); tests/test_lm_gpu.py compares both with the fp32 oracle.
 // ------------------------------------------------------------------------------------------------
-struct Q4Frag { const uint32_t* wfrag; const uint16_t* sbfrag; int sdt; };
+struct QFrag { const uint32_t* wfrag; const float* stfrag; };
+
+template <typename T> struct QMagic;
+template <> struct QMagic<BF16> { static constexpr uint32_t pair = 0x43004300u; static constexpr uint32_t one = 0x3f803f80u; };   // 128 + q; 1.0
+template <> struct QMagic<F16> { static constexpr uint32_t pair = 0x64006400u; static constexpr uint32_t one = 0x3c003c00u; };    // 1024 + q; 1.0
+
+// Epilogue of the transposed accumulator layout (activations are the MFMA's row operand here): lane (r, c) holds
+// C[m = m0 + 16 mt + 4 c + i][n = n0 + 16 t + r], i = 0..3 -- one output column per lane, so scale / offset are per-lane scalars.
+template <typename T, int MODE, int NT>
+__device__ __forceinline__ void skinny_store_tr(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane) {
+  const int r = lane & 15, c = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + r;
+    const bool nv = n < a.N;
+    const float bs = (MODE != SK_PARTIAL && a.bias && nv) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * mt + 4 * c + i;
+        float v = acc[t][mt][i] + bs;
+        if (MODE == SK_SWIGLU) {                 // interleaved rows: even column = gate, odd column = up (the neighbouring lane)
+          const float u = dpp_f32<0xB1>(v);      // quad_perm [1, 0, 3, 2]: every lane executes the exchange
+          if (nv && m < a.M && !(r & 1)) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + (n >> 1)] = T::from_f32((v / (1.0f + __expf(-v))) * u);
+          continue;
+        }
+        if (!nv || m >= a.M) continue;
+        if (MODE == SK_PARTIAL) reinterpret_cast<float*>(a.out)[((int64_t)split * a.M + m) * a.N + n] = acc[t][mt][i];
+        else if (MODE == SK_OUTF32) reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n] = v;
+        else reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + n] = T::from_f32(v);
+      }
+    }
+  }
+}
 
 // M16: at most 16 rows (single-sequence decode, small batches): the second 16-row MFMA half and its activation loads are skipped
-template <typename T, int MODE, int NT, int NW, bool M16>
-__global__ __launch_bounds__(64 * NW) void skinny_gemm_q4(SkinnyArgs a, Q4Frag q) {
+// NP: nibble planes per code (1 = 4-bit, 2 = 8-bit)
+template <typename T, int MODE, int NT, int NW, bool M16, int NP>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_qi(SkinnyArgs a, QFrag q) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile0 = blockIdx.x * NT;
@@ -671,55 +730,74 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_q4(SkinnyArgs a, Q4Frag q
   const int b0 = (split * NW + wave) * bc;
   const int n_tiles = (a.N + 15) >> 4;
   const int r = lane & 15, c = lane >> 4;
-  int am0 = m0 + r; am0 = am0 < a.M ? am0 : a.M - 1;
-  int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
-  const uint16_t* ap0 = a.A + (int64_t)am0 * a.lda + 8 * c;
-  const uint16_t* ap1 = a.A + (int64_t)am1 * a.lda + 8 * c;
+  // activations are the MFMA's ROW operand (lane r = row m0 + r): only lanes whose row exists fetch them (dec_skinny_gemm)
+  const bool av0 = m0 + r < a.M, av1 = !M16 && m0 + 16 + r < a.M;
+  const uint16_t* ap0 = a.A + (int64_t)(av0 ? m0 + r : 0) * a.lda + 8 * c;
+  const uint16_t* ap1 = a.A + (int64_t)(av1 ? m0 + 16 + r : 0) * a.lda + 8 * c;
   const u32x4* wp[NT];
-  const u32x2* sp[NT];
+  const f32x4* sp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tl = tile0 + t < n_tiles ? tile0 + t : n_tiles - 1;      // tiles past the end re-read the last one and are never stored
-    wp[t] = reinterpret_cast<const u32x4*>(q.wfrag) + ((int64_t)tl * nblk) * 64 + lane;
-    sp[t] = reinterpret_cast<const u32x2*>(q.sbfrag) + ((int64_t)tl * nblk) * 16 + r;
+    wp[t] = reinterpret_cast<const u32x4*>(q.wfrag) + ((int64_t)tl * nblk) * (NP * 64) + lane;
+    sp[t] = reinterpret_cast<const f32x4*>(q.stfrag) + ((int64_t)tl * nblk) * 16 + r;      // (s, t) of the block's two groups for column r
   }
   f32x4 acc[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  struct Blk { u32x4 w[NT]; u32x2 sb[NT]; s16x8 a0[4], a1[4]; };
+  const s16x8 zfrag = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  struct Blk { u32x4 w[NT][NP]; f32x4 st[NT]; s16x8 a0[4], a1[4]; };
   auto load_blk = [&](Blk& b, int blk) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { b.w[t] = wp[t][(int64_t)blk * 64]; b.sb[t] = sp[t][(int64_t)blk * 16]; }
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) b.w[t][p] = __builtin_nontemporal_load(wp[t] + ((int64_t)blk * NP + p) * 64);
+      b.st[t] = __builtin_nontemporal_load(sp[t] + (int64_t)blk * 16);
+    }
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      b.a0[st] = *reinterpret_cast<const s16x8*>(ap0 + (int64_t)blk * 128 + 32 * st);
-      if (!M16) b.a1[st] = *reinterpret_cast<const s16x8*>(ap1 + (int64_t)blk * 128 + 32 * st);
+      b.a0[st] = zfrag;
+      if (av0) b.a0[st] = *reinterpret_cast<const s16x8*>(ap0 + (int64_t)blk * 128 + 32 * st);
+      if (!M16) { b.a1[st] = zfrag; if (av1) b.a1[st] = *reinterpret_cast<const s16x8*>(ap1 + (int64_t)blk * 128 + 32 * st); }
     }
   };
-  auto cvt = [&](uint32_t h16) -> float { return q.sdt == MIA_F16 ? F16::to_f32((uint16_t)h16) : BF16::to_f32((uint16_t)h16); };
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const s16x8 ones = __builtin_bit_cast(s16x8, (u32x4){QMagic<T>::one, QMagic<T>::one, QMagic<T>::one, QMagic<T>::one});
+  auto unpack = [](uint32_t word) -> s16x8 {     // 8 codes -> 8 x (MAG + q) in K order
+    return __builtin_bit_cast(s16x8, (u32x4){(word & 0x000f000fu) | QMagic<T>::pair, ((word >> 4) & 0x000f000fu) | QMagic<T>::pair,
+                                             ((word >> 8) & 0x000f000fu) | QMagic<T>::pair, ((word >> 12) & 0x000f000fu) | QMagic<T>::pair});
+  };
   auto mma_blk = [&](const Blk& b) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const float sc[2] = {cvt(b.sb[t][0] & 0xffffu), cvt(b.sb[t][1] & 0xffffu)};
-      const float bs[2] = {cvt(b.sb[t][0] >> 16), cvt(b.sb[t][1] >> 16)};
+    for (int g = 0; g < 2; ++g) {
+      // A[i] = sum of the group's 64 activations of row 4 c + i
+      f32x4 A0 = T::mfma16(b.a0[2 * g], ones, zero4), A1 = zero4;
+      A0 = T::mfma16(b.a0[2 * g + 1], ones, A0);
+      if (!M16) { A1 = T::mfma16(b.a1[2 * g], ones, zero4); A1 = T::mfma16(b.a1[2 * g + 1], ones, A1); }
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const uint32_t word = b.w[t][st];
-        const float s1 = sc[st >> 1], b1 = bs[st >> 1];
-        uint32_t pk[4];
+      for (int t = 0; t < NT; ++t) {
+        f32x4 P0[NP], P1[NP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = __builtin_fmaf(s1, (float)((word >> (8 * j)) & 15u), b1);
-          const float hi = __builtin_fmaf(s1, (float)((word >> (8 * j + 4)) & 15u), b1);
-          pk[j] = pack2<T>(lo, hi);
+        for (int p = 0; p < NP; ++p) {
+          const s16x8 f0 = unpack(b.w[t][p][2 * g]), f1 = unpack(b.w[t][p][2 * g + 1]);
+          P0[p] = T::mfma16(b.a0[2 * g], f0, zero4);
+          P0[p] = T::mfma16(b.a0[2 * g + 1], f1, P0[p]);
+          if (!M16) { P1[p] = T::mfma16(b.a1[2 * g], f0, zero4); P1[p] = T::mfma16(b.a1[2 * g + 1], f1, P1[p]); }
         }
-        const s16x8 fw = __builtin_bit_cast(s16x8, (u32x4){pk[0], pk[1], pk[2], pk[3]});
-        acc[t][0] = T::mfma16(fw, b.a0[st], acc[t][0]);
-        if (!M16) acc[t][1] = T::mfma16(fw, b.a1[st], acc[t][1]);
+        const float sc = b.st[t][2 * g], tt = b.st[t][2 * g + 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p0 = NP == 2 ? __builtin_fmaf(16.0f, P0[NP - 1][i], P0[0][i]) : P0[0][i];
+          acc[t][0][i] = __builtin_fmaf(sc, p0, __builtin_fmaf(tt, A0[i], acc[t][0][i]));
+          if (!M16) {
+            const float p1 = NP == 2 ? __builtin_fmaf(16.0f, P1[NP - 1][i], P1[0][i]) : P1[0][i];
+            acc[t][1][i] = __builtin_fmaf(sc, p1, __builtin_fmaf(tt, A1[i], acc[t][1][i]));
+          }
+        }
       }
     }
   };
-  // ring of three register blocks (each 4 K-steps deep): two blocks of loads stay in flight behind the one being expanded
+  // ring of three register blocks (each 4 K-steps = two groups deep): two blocks of loads in flight behind the one being multiplied
   Blk k0, k1, k2;
   if (bc > 0) load_blk(k0, b0);
   if (bc > 1) load_blk(k1, b0 + 1);
@@ -734,7 +812,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_q4(SkinnyArgs a, Q4Frag q
     mma_blk(k2);
   }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_store<T, MODE, NT>(a, acc, n0, m0, split, lane);
+  skinny_store_tr<T, MODE, NT>(a, acc, n0, m0, split, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1399,43 +1477,48 @@ int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) 
 }
 
 
-template <typename T, bool M16>
-static void skinny_q4_launch_m(const SkinnyArgs& a, const Q4Frag& q, int mode, hipStream_t s) {
+template <typename T, bool M16, int NP>
+static void skinny_qi_launch_m(const SkinnyArgs& a, const QFrag& q, int mode, hipStream_t s) {
   const int tiles = (a.N + 15) / 16, nblk = a.K / 128;
-  const bool nw4 = nblk % (4 * a.S) == 0;
   const int zb = (a.M + 31) / 32;
-  // 4 tiles per wave whenever that still leaves every CU a workgroup: the activation fragments (the larger share of a wave's loads:
-  // 16 bits x 32 rows against 4 bits x 16 rows per tile) are then reused four times
-  const bool nt4 = mode == SK_OUTF32 || (int64_t)((tiles + 3) / 4) * a.S * zb >= 256;
-#define Q4_GO(MODE_, NT_, NW_) hipLaunchKernelGGL((skinny_gemm_q4<T, MODE_, NT_, NW_, M16>), dim3((tiles + NT_ - 1) / NT_, a.S, zb), dim3(64 * NW_), 0, s, a, q)
-#define Q4_LAUNCH(MODE_)                                                        \
-  do {                                                                          \
-    if (nt4) { if (nw4) Q4_GO(MODE_, 4, 4); else Q4_GO(MODE_, 4, 1); }           \
-    else { if (nw4) Q4_GO(MODE_, 1, 4); else Q4_GO(MODE_, 1, 1); }               \
+  const int per_split = nblk / a.S;               // 128-input blocks per cross-workgroup split
+  // 4 tiles per wave only when one tile per wave would put more than ~16 waves on every SIMD anyway (the vocabulary-wide head): the
+  // activation fragments and group sums are then reused four times.  Otherwise one tile per wave and as many waves per workgroup
+  // (1..4, splitting the K range) as keep 2+ blocks per wave -- the kernel hides its memory latency by occupancy.
+  const bool nt4 = (int64_t)tiles * a.S * zb >= 16384;
+  int nw = 1;
+  for (int cand : {4, 3, 2}) if (per_split % cand == 0 && (per_split / cand >= 2 || cand == 2)) { nw = cand; break; }
+#define QI_GO(MODE_, NT_, NW_) hipLaunchKernelGGL((skinny_gemm_qi<T, MODE_, NT_, NW_, M16, NP>), dim3((tiles + NT_ - 1) / NT_, a.S, zb), dim3(64 * NW_), 0, s, a, q)
+#define QI_LAUNCH(MODE_)                                                                                   \
+  do {                                                                                                     \
+    if (nt4) { if (per_split % 4 == 0) QI_GO(MODE_, 4, 4); else QI_GO(MODE_, 4, 1); }                       \
+    else if (nw == 4) QI_GO(MODE_, 1, 4); else if (nw == 3) QI_GO(MODE_, 1, 3);                             \
+    else if (nw == 2) QI_GO(MODE_, 1, 2); else QI_GO(MODE_, 1, 1);                                          \
   } while (0)
   switch (mode) {
-    case SK_OUTF32: Q4_GO(SK_OUTF32, 4, 1); break;      // vocabulary-wide head
-    case SK_OUT16: Q4_LAUNCH(SK_OUT16); break;
-    case SK_SWIGLU: Q4_LAUNCH(SK_SWIGLU); break;
-    default: Q4_LAUNCH(SK_PARTIAL); break;
+    case SK_OUTF32: QI_LAUNCH(SK_OUTF32); break;
+    case SK_OUT16: QI_LAUNCH(SK_OUT16); break;
+    case SK_SWIGLU: QI_LAUNCH(SK_SWIGLU); break;
+    default: QI_LAUNCH(SK_PARTIAL); break;
   }
-#undef Q4_LAUNCH
-#undef Q4_GO
+#undef QI_LAUNCH
+#undef QI_GO
 }
 
 template <typename T>
-static void skinny_q4_launch_t(const SkinnyArgs& a, const Q4Frag& q, int mode, hipStream_t s) {
-  if (a.M <= 16) skinny_q4_launch_m<T, true>(a, q, mode, s); else skinny_q4_launch_m<T, false>(a, q, mode, s);
+static void skinny_qi_launch_t(const SkinnyArgs& a, const QFrag& q, int bits, int mode, hipStream_t s) {
+  if (bits == 8) { if (a.M <= 16) skinny_qi_launch_m<T, true, 2>(a, q, mode, s); else skinny_qi_launch_m<T, false, 2>(a, q, mode, s); }
+  else { if (a.M <= 16) skinny_qi_launch_m<T, true, 1>(a, q, mode, s); else skinny_qi_launch_m<T, false, 1>(a, q, mode, s); }
 }
 
-// 4-bit form of skinny_gemm_launch: a.W is ignored, the weights come from the fragment-ordered arrays (see skinny_gemm_q4)
-int skinny_gemm_q4_launch(const SkinnyArgs& a, const uint32_t* wfrag, const uint16_t* sbfrag, int scale_dtype, int mode, int dtype, hipStream_t s) {
-  if (a.K % (128 * a.S) != 0 || a.lda % 8 != 0 || !wfrag || !sbfrag) return -1;
-  if (scale_dtype != MIA_F16 && scale_dtype != MIA_BF16) return -1;
+// quantised form of skinny_gemm_launch: a.W is ignored, the weights come from the fragment-ordered arrays (see skinny_gemm_qi)
+int skinny_gemm_q_launch(const SkinnyArgs& a, const uint32_t* wfrag, const float* stfrag, int bits, int mode, int dtype, hipStream_t s) {
+  if (a.K % (128 * a.S) != 0 || a.lda % 8 != 0 || !wfrag || !stfrag) return -1;
+  if (bits != 4 && bits != 8) return -1;
   if (mode != SK_OUT16 && mode != SK_OUTF32 && mode != SK_PARTIAL && mode != SK_SWIGLU) return -1;
   if (mode == SK_SWIGLU && (a.N & 3)) return -1;
-  const Q4Frag q{wfrag, sbfrag, scale_dtype};
-  if (dtype == MIA_F16) skinny_q4_launch_t<F16>(a, q, mode, s); else skinny_q4_launch_t<BF16>(a, q, mode, s);
+  const QFrag q{wfrag, stfrag};
+  if (dtype == MIA_F16) skinny_qi_launch_t<F16>(a, q, bits, mode, s); else skinny_qi_launch_t<BF16>(a, q, bits, mode, s);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -24,8 +24,8 @@ struct LmState { int pos; int n_hist; int finished; int n_gen; int n_embeds; int
 
 struct RasParams { float top_p; int top_k; int win; float tau; int eos; int min_len; int max_len; int n_uniforms; };
 
-// MLX-affine 4-bit copy of one fused matrix in MFMA fragment order (decode_kernels.hip: skinny_gemm_q4); null = use the 16-bit weights
-struct Q4W { uint32_t* wfrag = nullptr; uint16_t* sbfrag = nullptr; };
+// MLX-affine 4- / 8-bit copy of one fused matrix in MFMA fragment order (decode_kernels.hip: skinny_gemm_qi); null = use the 16-bit weights
+struct Q4W { uint32_t* wfrag = nullptr; float* stfrag = nullptr; };
 
 struct LmLayer {
   Q4W q_qkv, q_o, q_gu, q_down;
@@ -49,7 +49,7 @@ struct mia_lm {
   void* lm_head = nullptr;      // 16-bit [V][hidden] (== embed when tied)
   void* lm_head_f = nullptr;    // lm_head in MFMA-fragment order (decode step)
   Q4W q_head;                   // 4-bit copy of lm_head (mia_lm_attach_q4)
-  int q4_scale_dtype = 0;       // MIA_F16 | MIA_BF16: storage type of the checkpoint's scales / biases
+  int q_bits = 0;               // 4 | 8 once packed weights are attached (mia_lm_attach_quantized), 0 = none
   bool q4 = false;              // the step GEMVs stream the packed weights
   float* head_bias = nullptr;   // optional (CosyVoice2 llm_decoder)
   int head_vocab = 0;           // rows of lm_head (CosyVoice2: speech vocabulary + 3)
@@ -976,7 +976,7 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
   auto skinny = [&](const void* A, int64_t lda, const void* W, const void* Wf, const float* bias, void* out, int64_t ldo, int N, int K, int S, int mode,
                     const Q4W* qw = nullptr) {
     SkinnyArgs a{(const uint16_t*)A, lda, (const uint16_t*)W, bias, out, ldo, nullptr, nullptr, nullptr, nb, N, K, S, MIA_ACT_NONE, 0, 0, 0};
-    if (m->q4 && qw && qw->wfrag) return skinny_gemm_q4_launch(a, qw->wfrag, qw->sbfrag, m->q4_scale_dtype, mode, m->dtype, s);
+    if (m->q4 && qw && qw->wfrag) return skinny_gemm_q_launch(a, qw->wfrag, qw->stfrag, m->q_bits, mode, m->dtype, s);
     if (Wf) { a.W = (const uint16_t*)Wf; a.w_frag = 1; }      // same K order and partition as the row-major form: identical results
     return skinny_gemm_launch(a, mode, m->dtype, s);
   };
@@ -1261,13 +1261,20 @@ extern "C" mia_lm* mia_lm_load(mia_ctx* ctx, const mia_lm_config* cfg, const mia
 // ---- MLX-affine 4-bit weights for the decode step (OrpheusWeightLoader.swift:28-60: the reference's default checkpoints are q4, group 64) ----
 namespace {
 
-struct Q4Src { const uint32_t* w; const uint16_t* s; const uint16_t* b; };   // one Linear as stored: packed [N][K/8], scales / biases [N][K/64]
+struct Q4Src { const uint32_t* w; const uint16_t* s; const uint16_t* b; };   // one Linear as stored: packed [N][K*bits/32], scales / biases [N][K/64]
 
-// rows[i] = (tensor index, row): the fused matrix's row i.  Builds the fragment-ordered arrays (layout: skinny_gemm_q4) and uploads them.
-bool q4_repack(LmLoader& L, const std::vector<Q4Src>& src, const std::vector<std::pair<int, int>>& rows, int K, Q4W& out) {
-  const int N = (int)rows.size(), tiles = (N + 15) / 16, nblk = K / 128, wpr = K / 8, gpr = K / 64;
-  std::vector<uint32_t> wf((size_t)tiles * nblk * 64 * 4);
-  std::vector<uint16_t> sb((size_t)tiles * nblk * 16 * 4);
+float q16_to_f32(uint16_t v, int sdt) {
+  if (sdt == MIA_F16) { _Float16 h; memcpy(&h, &v, 2); return (float)h; }
+  const uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f;
+}
+
+// rows[i] = (tensor index, row): the fused matrix's row i.  Builds the fragment-ordered arrays (layout and arithmetic: skinny_gemm_qi)
+// and uploads them.  bits 4 | 8; mag = the 16-bit float the codes are OR-ed into (128 for bf16, 1024 for f16 compute).
+bool q_repack(LmLoader& L, const std::vector<Q4Src>& src, const std::vector<std::pair<int, int>>& rows, int K, int bits, int sdt, float mag, Q4W& out) {
+  const int N = (int)rows.size(), tiles = (N + 15) / 16, nblk = K / 128, np = bits / 4, cpw = 32 / bits, wpr = K / cpw, gpr = K / 64;
+  std::vector<uint32_t> wf((size_t)tiles * nblk * np * 64 * 4);
+  std::vector<float> st((size_t)tiles * nblk * 16 * 4);
+  const float tmul = mag * (np == 2 ? 17.0f : 1.0f);
   for (int t = 0; t < tiles; ++t)
     for (int r = 0; r < 16; ++r) {
       const int n = std::min(t * 16 + r, N - 1);                      // the last tile repeats its final row (never stored)
@@ -1275,44 +1282,63 @@ bool q4_repack(LmLoader& L, const std::vector<Q4Src>& src, const std::vector<std
       const uint32_t* wrow = q.w + (size_t)rows[n].second * wpr;
       const uint16_t* srow = q.s + (size_t)rows[n].second * gpr;
       const uint16_t* brow = q.b + (size_t)rows[n].second * gpr;
+      auto code = [&](int k) -> uint32_t { return (wrow[k / cpw] >> ((k % cpw) * bits)) & ((1u << bits) - 1u); };   // MLX packing: little end first
       for (int b = 0; b < nblk; ++b) {
         for (int c = 0; c < 4; ++c)
-          for (int st = 0; st < 4; ++st) wf[(((size_t)t * nblk + b) * 64 + 16 * c + r) * 4 + st] = wrow[b * 16 + 4 * st + c];
-        uint16_t* d = &sb[(((size_t)t * nblk + b) * 16 + r) * 4];
-        d[0] = srow[2 * b]; d[1] = brow[2 * b]; d[2] = srow[2 * b + 1]; d[3] = brow[2 * b + 1];
+          for (int stp = 0; stp < 4; ++stp) {
+            const int k0 = b * 128 + 32 * stp + 8 * c;
+            for (int p = 0; p < np; ++p) {
+              uint32_t word = 0;
+              for (int i = 0; i < 4; ++i) {
+                const uint32_t q0 = (code(k0 + 2 * i) >> (4 * p)) & 15u, q1 = (code(k0 + 2 * i + 1) >> (4 * p)) & 15u;
+                word |= (q0 << (4 * i)) | (q1 << (16 + 4 * i));
+              }
+              wf[((((size_t)t * nblk + b) * np + p) * 64 + 16 * c + r) * 4 + stp] = word;
+            }
+          }
+        for (int g = 0; g < 2; ++g) {
+          const float sc = q16_to_f32(srow[2 * b + g], sdt), bi = q16_to_f32(brow[2 * b + g], sdt);
+          float* d = &st[(((size_t)t * nblk + b) * 16 + r) * 4 + 2 * g];
+          d[0] = sc;
+          d[1] = (float)((double)bi - (double)tmul * (double)sc);
+        }
       }
     }
   out.wfrag = (uint32_t*)L.dev(wf.size() * 4);
-  out.sbfrag = (uint16_t*)L.dev(sb.size() * 2);
-  if (!out.wfrag || !out.sbfrag) return false;
-  (void)hipMemcpy(out.wfrag, wf.data(), wf.size() * 4, hipMemcpyHostToDevice);
-  (void)hipMemcpy(out.sbfrag, sb.data(), sb.size() * 2, hipMemcpyHostToDevice);
+  out.stfrag = (float*)L.dev(st.size() * 4);
+  if (!out.wfrag || !out.stfrag) { if (L.err.empty()) L.err = "hipMalloc failed for the packed weights"; return false; }
+  if (hipMemcpy(out.wfrag, wf.data(), wf.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(out.stfrag, st.data(), st.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    if (L.err.empty()) L.err = "upload of the packed weights failed";
+    return false;
+  }
   return true;
 }
 
 }  // namespace
 
-// tensors: for every Linear of the step, `<name>.weight` (MIA_U32 packed codes [N][K/8]), `<name>.scales`, `<name>.biases` ([N][K/64],
-// both MIA_F16 or both MIA_BF16), names as in the checkpoint (model.layers.L.self_attn.{q,k,v,o}_proj, mlp.{gate,up,down}_proj,
+// tensors: for every Linear of the step, `<name>.weight` (MIA_U32 packed codes [N][K * bits / 32]), `<name>.scales`, `<name>.biases`
+// ([N][K/64], both MIA_F16 or both MIA_BF16), names as in the checkpoint (model.layers.L.self_attn.{q,k,v,o}_proj, mlp.{gate,up,down}_proj,
 // model.embed_tokens / lm_head).  The handle must already hold the de-quantised 16-bit weights (mia_lm_load on the expanded
 // checkpoint): the batched prompt pass keeps using them, the per-token step switches to the packed form.
-extern "C" int mia_lm_attach_q4(mia_lm* m, const mia_tensor_view* tensors, int n_tensors, int group_size) {
+extern "C" int mia_lm_attach_quantized(mia_lm* m, const mia_tensor_view* tensors, int n_tensors, int group_size, int bits) {
   if (!m) return MIA_ERR_MODEL_NOT_LOADED;
   mia_ctx* ctx = m->ctx;
-  MIA_CHECK_ARG(ctx, tensors && n_tensors > 0 && group_size == 64, "lm_attach_q4: tensors required, group size must be 64");
+  MIA_CHECK_ARG(ctx, tensors && n_tensors > 0 && group_size == 64 && (bits == 4 || bits == 8), "lm_attach_quantized: tensors required, group size 64, 4 or 8 bits");
+  MIA_CHECK_ARG(ctx, m->q_bits == 0, "lm_attach_quantized: packed weights are already attached to this handle (load a fresh handle to replace them)");
   const mia_lm_config& c = m->cfg;
   const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh;
-  MIA_CHECK_ARG(ctx, D % 128 == 0 && Nq % 128 == 0 && c.inter % 128 == 0, "lm_attach_q4: hidden, n_heads*head_dim and inter must be multiples of 128");
+  MIA_CHECK_ARG(ctx, D % 128 == 0 && Nq % 128 == 0 && c.inter % 128 == 0, "lm_attach_quantized: hidden, n_heads*head_dim and inter must be multiples of 128");
   MIA_HIP(ctx, hipSetDevice(ctx->device));
   LmLoader L; L.m = m;
   for (int i = 0; i < n_tensors; ++i) if (tensors[i].name && tensors[i].data) L.by_name[tensors[i].name] = &tensors[i];
   int sdt = 0;
+  const float mag = m->dtype == MIA_F16 ? 1024.0f : 128.0f;
   auto get = [&](const std::string& p, int N, int K, Q4Src& q) -> bool {
     const mia_tensor_view* w = L.find(p + ".weight"); const mia_tensor_view* s = L.find(p + ".scales"); const mia_tensor_view* b = L.find(p + ".biases");
     if (!w || !s || !b) return false;
-    const bool ok = w->dtype == MIA_U32 && w->ndim == 2 && w->shape[0] == N && w->shape[1] == K / 8 && s->ndim == 2 && s->shape[0] == N && s->shape[1] == K / 64 &&
+    const bool ok = w->dtype == MIA_U32 && w->ndim == 2 && w->shape[0] == N && w->shape[1] == (int64_t)K * bits / 32 && s->ndim == 2 && s->shape[0] == N && s->shape[1] == K / 64 &&
                     b->ndim == 2 && b->shape[0] == N && b->shape[1] == K / 64 && s->dtype == b->dtype && (s->dtype == MIA_F16 || s->dtype == MIA_BF16);
-    if (!ok) { if (L.err.empty()) L.err = "'" + p + "' is not a 4-bit group-64 Linear of the expected shape (scales / biases must be f16 or bf16)"; return false; }
+    if (!ok) { if (L.err.empty()) L.err = "'" + p + "' is not a " + std::to_string(bits) + "-bit group-64 Linear of the expected shape (scales / biases must be f16 or bf16)"; return false; }
     if (sdt == 0) sdt = s->dtype;
     if (sdt != s->dtype) { if (L.err.empty()) L.err = "mixed scale dtypes"; return false; }
     q = Q4Src{(const uint32_t*)w->data, (const uint16_t*)s->data, (const uint16_t*)b->data};
@@ -1326,34 +1352,44 @@ extern "C" int mia_lm_attach_q4(mia_lm* m, const mia_tensor_view* tensors, int n
     std::vector<std::pair<int, int>> rows;
     if (get(p + ".self_attn.q_proj", Nq, D, src[0]) && get(p + ".self_attn.k_proj", Nk, D, src[1]) && get(p + ".self_attn.v_proj", Nk, D, src[2])) {
       seq(0, Nq, rows); seq(1, Nk, rows); seq(2, Nk, rows);
-      if (!q4_repack(L, src, rows, D, ly.q_qkv)) break;
+      if (!q_repack(L, src, rows, D, bits, sdt, mag, ly.q_qkv)) break;
     }
     src.assign(1, Q4Src{}); rows.clear();
-    if (get(p + ".self_attn.o_proj", D, Nq, src[0])) { seq(0, D, rows); if (!q4_repack(L, src, rows, Nq, ly.q_o)) break; }
+    if (get(p + ".self_attn.o_proj", D, Nq, src[0])) { seq(0, D, rows); if (!q_repack(L, src, rows, Nq, bits, sdt, mag, ly.q_o)) break; }
     src.assign(2, Q4Src{}); rows.clear();
     if (get(p + ".mlp.gate_proj", c.inter, D, src[0]) && get(p + ".mlp.up_proj", c.inter, D, src[1])) {
       for (int i = 0; i < c.inter; ++i) { rows.push_back({0, i}); rows.push_back({1, i}); }      // gate / up rows interleaved like wgu
-      if (!q4_repack(L, src, rows, D, ly.q_gu)) break;
+      if (!q_repack(L, src, rows, D, bits, sdt, mag, ly.q_gu)) break;
     }
     src.assign(1, Q4Src{}); rows.clear();
-    if (get(p + ".mlp.down_proj", D, c.inter, src[0])) { seq(0, D, rows); if (!q4_repack(L, src, rows, c.inter, ly.q_down)) break; }
+    if (get(p + ".mlp.down_proj", D, c.inter, src[0])) { seq(0, D, rows); if (!q_repack(L, src, rows, c.inter, bits, sdt, mag, ly.q_down)) break; }
   }
   if (L.err.empty() && m->head_vocab == 0) {     // the tied / plain LM head (the CosyVoice2 speech head stays 16-bit: it is not quantised there)
     std::vector<Q4Src> src(1);
     std::vector<std::pair<int, int>> rows;
     const std::string hp = c.tie_embeddings ? "model.embed_tokens" : "lm_head";
-    if (L.find(hp + ".scales", false)) { if (get(hp, c.vocab, D, src[0])) { seq(0, c.vocab, rows); q4_repack(L, src, rows, D, m->q_head); } }
+    if (L.find(hp + ".scales", false)) { if (get(hp, c.vocab, D, src[0])) { seq(0, c.vocab, rows); q_repack(L, src, rows, D, bits, sdt, mag, m->q_head); } }
   }
-  if (!L.err.empty()) return mia_fail(ctx, MIA_ERR_INVALID_ARGUMENT, "lm_attach_q4: %s", L.err.c_str());
+  if (!L.err.empty()) {
+    // a partly packed handle must not run: drop every packed pointer (the buffers stay with the handle's allocation list until mia_lm_free)
+    for (LmLayer& ly : m->layers) { ly.q_qkv = Q4W{}; ly.q_o = Q4W{}; ly.q_gu = Q4W{}; ly.q_down = Q4W{}; }
+    m->q_head = Q4W{};
+    const bool oom = L.err.find("hipMalloc") != std::string::npos;
+    return mia_fail(ctx, oom ? MIA_ERR_OUT_OF_MEMORY : MIA_ERR_INVALID_ARGUMENT, "lm_attach_quantized: %s", L.err.c_str());
+  }
   MIA_HIP(ctx, hipDeviceSynchronize());
   // the packed kernel splits K in 128-input blocks: re-pick the cross-workgroup splits on that granule (the 16-bit step uses the same
-  // splits from here on, so switching between the two forms never changes a summation order)
+  // splits from here on)
   auto split128 = [](int K, int want) { for (int sp = want; sp > 1; --sp) if (K % (128 * sp) == 0) return sp; return 1; };
   m->S_qkv = split128(D, 4); m->S_o = split128(Nq, 4); m->S_down = split128(c.inter, 8);
-  m->q4_scale_dtype = sdt;
+  m->q_bits = bits;
   m->q4 = true;
   m->graph_mode = -1;          // the captured step holds the 16-bit launches: re-capture
   return MIA_OK;
+}
+
+extern "C" int mia_lm_attach_q4(mia_lm* m, const mia_tensor_view* tensors, int n_tensors, int group_size) {
+  return mia_lm_attach_quantized(m, tensors, n_tensors, group_size, 4);
 }
 
 // switch the step between the packed (1) and the 16-bit (0) weights of a handle that has both (A/B timing, parity tests)
@@ -1366,7 +1402,7 @@ extern "C" int mia_lm_set_debug(mia_lm* m, int flags) {
 
 extern "C" int mia_lm_use_q4(mia_lm* m, int on) {
   if (!m) return MIA_ERR_MODEL_NOT_LOADED;
-  MIA_CHECK_ARG(m->ctx, !on || m->q4_scale_dtype != 0, "lm_use_q4: no packed weights attached");
+  MIA_CHECK_ARG(m->ctx, !on || m->q_bits != 0, "lm_use_q4: no packed weights attached");
   m->q4 = on != 0;
   m->graph_mode = -1;
   return MIA_OK;

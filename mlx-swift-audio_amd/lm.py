@@ -73,13 +73,13 @@ class CausalLM:
             raise _lib.MiaError(_lib.ERR_INVALID_ARGUMENT, ctx.lib.mia_last_error(ctx.h).decode())
         return CausalLM(ctx, h, cfg)
 
-    def attach_q4(self, packed: dict[str, np.ndarray], group_size: int = 64) -> None:
-        """mia_lm_attach_q4: `packed` holds every step Linear as the checkpoint stores it -- `<name>.weight` uint32 codes,
+    def attach_q4(self, packed: dict[str, np.ndarray], group_size: int = 64, bits: int = 4) -> None:
+        """mia_lm_attach_quantized (bits 4 | 8): `packed` holds every step Linear as the checkpoint stores it -- `<name>.weight` uint32 codes,
         `<name>.scales` / `<name>.biases` float16 (or uint16 arrays tagged .st_dtype == "BF16", as checkpoint.read_safetensors returns
         bf16 payloads).  The handle must have been loaded from the de-quantised tensors of the same checkpoint."""
         lib = self.ctx.lib
-        lib.mia_lm_attach_q4.restype = C.c_int
-        lib.mia_lm_attach_q4.argtypes = [C.c_void_p, C.POINTER(_TensorView), C.c_int, C.c_int]
+        lib.mia_lm_attach_quantized.restype = C.c_int
+        lib.mia_lm_attach_quantized.argtypes = [C.c_void_p, C.POINTER(_TensorView), C.c_int, C.c_int, C.c_int]
         views = (_TensorView * len(packed))()
         keep = []
         for i, (name, arr) in enumerate(packed.items()):
@@ -95,7 +95,14 @@ class CausalLM:
             keep.append(a)
             shp = (C.c_int64 * 4)(*(list(a.shape) + [0] * (4 - a.ndim)))
             views[i] = _TensorView(name.encode(), dt, a.ndim, shp, a.ctypes.data)
-        self.ctx.check(lib.mia_lm_attach_q4(self.h, views, len(packed), group_size))
+        self.ctx.check(lib.mia_lm_attach_quantized(self.h, views, len(packed), group_size, bits))
+
+    def set_debug(self, flags: int) -> None:
+        """Test hook (mia_lm_set_debug): bit 0 = no hipGraph, bit 1 = prompts token by token (no batched prompt pass)."""
+        lib = self.ctx.lib
+        lib.mia_lm_set_debug.restype = C.c_int
+        lib.mia_lm_set_debug.argtypes = [C.c_void_p, C.c_int]
+        self.ctx.check(lib.mia_lm_set_debug(self.h, int(flags)))
 
     def use_q4(self, on: bool) -> None:
         lib = self.ctx.lib

@@ -273,10 +273,10 @@ def test_ras_top_k_with_exact_ties(ctx, n_tied):
     model.close()
 
 
-def _quantized_checkpoint(cfg, seed, scale_dtype=np.float16):
-    """A q4 / group-64 checkpoint in the MLX layout plus its de-quantised tensors: every step Linear (and the tied embedding) of a seeded
-    random-init model is quantised with the test-side restatement of mx.quantize (oracle/quant.py), scales / biases rounded to the
-    16-bit type a checkpoint stores them in."""
+def _quantized_checkpoint(cfg, seed, scale_dtype=np.float16, bits=4):
+    """A q4 / q8 group-64 checkpoint in the MLX layout plus its de-quantised tensors: every step Linear (and the tied embedding) of a
+    seeded random-init model is quantised with the test-side restatement of mx.quantize (oracle/quant.py), scales / biases rounded to
+    the 16-bit type a checkpoint stores them in."""
     from oracle import quant as OQ
     w = S.lm_weights(cfg, seed=seed)
     packed, dense = {}, dict(w)
@@ -285,84 +285,113 @@ def _quantized_checkpoint(cfg, seed, scale_dtype=np.float16):
         p = f"model.layers.{l}"
         names += [p + ".self_attn." + n + "_proj" for n in "qkvo"] + [p + ".mlp." + n + "_proj" for n in ("gate", "up", "down")]
     for n in names:
-        pk, sc, bi = OQ.quantize_affine(w[n + ".weight"], 64, 4)
+        pk, sc, bi = OQ.quantize_affine(w[n + ".weight"], 64, bits)
         sc, bi = sc.astype(scale_dtype), bi.astype(scale_dtype)
         packed[n + ".weight"], packed[n + ".scales"], packed[n + ".biases"] = pk, sc, bi
-        dense[n + ".weight"] = OQ.dequantize_affine(pk, sc.astype(np.float32), bi.astype(np.float32), 64, 4)
+        dense[n + ".weight"] = OQ.dequantize_affine(pk, sc.astype(np.float32), bi.astype(np.float32), 64, bits)
     return packed, dense
 
 
-@pytest.mark.parametrize("cfg_name,dtype_name", [("llama-micro128", "bf16"), ("qwen-micro", "f16")])
-def test_q4_step_equals_expanded_checkpoint(ctx, cfg_name, dtype_name):
-    """Packed MLX-affine 4-bit step (mia_lm_attach_q4: 4.5 bits per weight streamed, expanded in registers) vs the SAME checkpoint expanded
-    to 16 bit at load: the expansion is value for value the same and the K order of every accumulation is the dense kernel's, so the
-    logits must be IDENTICAL, step after step, for one sequence and for a batch; and both must sit on the fp32 oracle of the
-    de-quantised weights within the usual 16-bit tolerance."""
+def _sampled_ids_follow_oracle(gen, ora, prompt, kw, u, tol):
+    """gen == the oracle's run on the same weights, or the first difference sits at a draw whose uniform is within `tol` of a CDF edge /
+    the top-p cut in the ORACLE (oracle/lm.py:sample_boundary_distance); after a proven fork the comparison stops."""
+    trace = []
+    want = OL.generate(ora, prompt, dict(kw), u, trace)
+    k = next((i for i, (a, b) in enumerate(zip(gen, want)) if a != b), min(len(gen), len(want)))
+    if not (k == len(gen) == len(want)):
+        assert min(trace[k]) < tol, (k, trace[k], gen, want)
+
+
+@pytest.mark.parametrize("cfg_name,dtype_name,bits", [("llama-micro128", "bf16", 4), ("qwen-micro", "f16", 4), ("llama-micro128", "bf16", 8), ("qwen-micro", "f16", 8)])
+def test_packed_step_matches_oracle_and_expanded_checkpoint(ctx, cfg_name, dtype_name, bits):
+    """Packed MLX-affine 4- / 8-bit step (mia_lm_attach_quantized: the codes go through the MFMA as exact 16-bit integers, scale and bias
+    are applied per 64-input group to fp32 group sums -- MLX's own qmv arithmetic) against (i) the fp32 oracle on the de-quantised
+    weights, which is what that arithmetic computes up to 16-bit activations, and (ii) the 16-bit step of the SAME handle on the
+    checkpoint expanded at load, which additionally rounds every de-quantised weight to 16 bit: the two must agree to that rounding
+    (a few 1e-3 of the logit spread), step after step, and the packed step must sit at least as close to the oracle."""
     import mlx_swift_audio_amd as m
     from mlx_swift_audio_amd import lm as HL
     cfg = S.LM_CONFIGS[cfg_name]
-    packed, dense = _quantized_checkpoint(cfg, seed=11)
+    packed, dense = _quantized_checkpoint(cfg, seed=11, bits=bits)
     model = HL.CausalLM.load(ctx, cfg, dense, _dt(dtype_name))
     ids = np.random.default_rng(2).integers(0, cfg.vocab, 9).tolist()
-    model.attach_q4(packed)
+    model.attach_q4(packed, bits=bits)
+    with pytest.raises(m.MiaError):
+        model.attach_q4(packed, bits=bits)          # one attach per handle
     model.use_q4(False)                             # the 16-bit weights of the same handle (same cross-workgroup splits)
     ref_steps = []
     for t in ids:                                   # token by token: every call is one step graph launch
         ref_steps.append(model.forward([t]).copy())
     model.use_q4(True)
     model.reset()
-    for t, want in zip(ids, ref_steps):
-        got = model.forward([t])
-        assert np.array_equal(got, want), np.abs(got - want).max()
-    ora = OL.LMOracle(cfg, {k: S.round_array(v, dtype_name) if v.ndim == 2 else v for k, v in dense.items()})
-    ref = ora.forward(ids).numpy()[-1]
-    assert np.abs(ref_steps[-1] - ref).max() <= 0.08 * ref.std()
-    # sampled generation, packed vs 16-bit: same ids
+    q_steps = [model.forward([t]).copy() for t in ids]
+    ora = OL.LMOracle(cfg, dense)                   # fp32 de-quantised weights, NOT rounded to 16 bit
+    ref = ora.forward(ids).numpy()
+    tol16 = 0.08 if dtype_name == "bf16" else 0.02
+    for i, (got, want) in enumerate(zip(q_steps, ref_steps)):
+        sd = ref[i].std()
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= (0.06 if dtype_name == "bf16" else 0.01) * sd, (i, np.abs(got - want).max(), sd)   # the expanded checkpoint's weight rounding
+        assert np.abs(got - ref[i]).max() <= tol16 * sd, (i, np.abs(got - ref[i]).max(), sd)
+    # sampled generation on the packed step follows the oracle under the boundary rule
     u = np.random.default_rng(4).random(20).astype(np.float32)
     kw = dict(temperature=0.7, top_p=0.9, rep_penalty=1.2, rep_window=16, max_new_tokens=20, stop_ids=(cfg.vocab - 1,))
-    a = model.generate(ids, u, **kw)
-    model.use_q4(False)
-    b = model.generate(ids, u, **kw)
-    assert a == b
-    model.use_q4(True)
+    _sampled_ids_follow_oracle(model.generate(ids, u, **kw), ora, ids, kw, u, 2e-2 if dtype_name == "bf16" else 5e-3)
+    # batched: sequence b of a batch equals its own single-sequence run (same kernels, rows side by side).  Prompts go token by token
+    # through the packed step here: the batched prompt pass runs on the 16-bit copy (weights rounded), and whether a prompt takes it
+    # depends on how many rows a call has -- a batch and a single run would otherwise differ by that rounding
+    model.set_debug(2)
     model.set_batch(4)
     prompts = [ids, ids[:3], ids[2:], ids[::-1]]
     ub = np.random.default_rng(5).random((4, 12)).astype(np.float32)
     kw["max_new_tokens"] = 12
     qa = model.generate_batch(prompts, ub, **kw)
-    model.use_q4(False)
-    assert model.generate_batch(prompts, ub, **kw) == qa
-    with pytest.raises(m.MiaError):
-        model.attach_q4({k: v for k, v in packed.items() if "q_proj" not in k})     # an incomplete set is rejected
+    model.set_batch(1)
+    for b, pr in enumerate(prompts):
+        assert model.generate(pr, ub[b], **kw) == qa[b], b
     model.close()
+    # an incomplete tensor set is rejected and leaves the handle on its 16-bit weights
+    fresh = HL.CausalLM.load(ctx, cfg, dense, _dt(dtype_name))
+    with pytest.raises(m.MiaError):
+        fresh.attach_q4({k: v for k, v in packed.items() if "q_proj" not in k}, bits=bits)
+    with pytest.raises(m.MiaError):
+        fresh.use_q4(True)
+    assert np.array_equal(fresh.forward(ids[:1]), ref_steps[0])
+    fresh.close()
 
 
-def test_q4_step_mid_size_batch_32(ctx):
-    """The packed step at a shape that exercises what the micro models cannot: several 128-input blocks per wave (the 3-deep register ring),
-    4-wave workgroups, cross-workgroup K splits, the 4-tile head and a FULL 32-row batch (both 16-row MFMA halves).  32 sequences decoded
-    side by side must give, sequence by sequence, the ids of the 16-bit step on the same de-quantised weights."""
+@pytest.mark.parametrize("bits", [4, 8])
+def test_packed_step_mid_size_batch_32(ctx, bits):
+    """The packed step at a shape that exercises what the micro models cannot: several 128-input blocks per wave (the register ring),
+    4-wave workgroups, cross-workgroup K splits, the 4-tile head and a FULL 32-row batch (both 16-row MFMA halves).  Logits against the
+    16-bit step on the de-quantised weights and the fp32 oracle; 32 sequences side by side give, sequence by sequence, the ids of their
+    own single-sequence runs."""
     import mlx_swift_audio_amd as m
     from mlx_swift_audio_amd import lm as HL
     cfg = S.LM_CONFIGS["llama-q4mid"]
-    packed, dense = _quantized_checkpoint(cfg, seed=21)
+    packed, dense = _quantized_checkpoint(cfg, seed=21, bits=bits)
     model = HL.CausalLM.load(ctx, cfg, dense, m.BF16)
-    model.attach_q4(packed)
+    model.attach_q4(packed, bits=bits)
     rng = np.random.default_rng(6)
     ids = rng.integers(0, cfg.vocab, 12).tolist()
     model.use_q4(False)
     want = [model.forward([t]).copy() for t in ids]
     model.use_q4(True)
     model.reset()
-    for t, w_ in zip(ids, want):
+    ref = OL.LMOracle(cfg, dense).forward(ids).numpy()
+    for i, (t, w_) in enumerate(zip(ids, want)):
         got = model.forward([t])
-        assert np.isfinite(got).all() and np.array_equal(got, w_), np.abs(got - w_).max()
+        sd = ref[i].std()
+        assert np.isfinite(got).all() and np.abs(got - w_).max() <= 0.06 * sd, (i, np.abs(got - w_).max(), sd)
+        assert np.abs(got - ref[i]).max() <= 0.08 * sd, (i, np.abs(got - ref[i]).max(), sd)
+    model.set_debug(2)              # prompts token by token through the packed step (see the test above)
     model.set_batch(32)
     prompts = [rng.integers(0, cfg.vocab, int(n)).tolist() for n in rng.integers(1, 20, 32)]
     ub = rng.random((32, 16)).astype(np.float32)
     kw = dict(temperature=0.8, top_p=0.9, rep_penalty=1.1, rep_window=8, max_new_tokens=16, stop_ids=(cfg.vocab - 1,))
     q = model.generate_batch(prompts, ub, **kw)
-    model.use_q4(False)
-    d = model.generate_batch(prompts, ub, **kw)
-    assert q == d
     assert all(0 <= t < cfg.vocab for seq in q for t in seq)
+    model.set_batch(1)
+    for b in (0, 7, 31):            # rows of a 32-row batch (M > 16: both MFMA halves) equal the single-sequence (M16) kernel's ids
+        assert model.generate(prompts[b], ub[b], **kw) == q[b], b
     model.close()
