@@ -15,6 +15,11 @@
 //     workgroup.
 // Pass 2 (logmel_pass2): clamp to (clip max - 8), (x+4)/4, cast, and scatter into the consumer's layout
 //   (dense time-major, channel-major for S3, or the zero-row-padded layout the encoder's conv1 reads).
+// Time-major outputs (the Whisper path) skip the fp32 round trip: pass 1 stores the FINAL value (x+4)/4 in the output type straight into
+//   the consumer's layout, and only the clamp is left for afterwards.  Clamping commutes with the monotonic map and the rounding:
+//   max(rnd((v+4)/4), rnd((c+4)/4)) == rnd((max(v, c)+4)/4), so logmel_clampfix rewrites -- in place, in the output type -- only the
+//   32-frame blocks whose smallest value lies below the clip's floor (pass 1 records each block's minimum) plus the rows past the audio.
+//   Traffic: audio once + output once (+ the few blocks that need the clamp) instead of + an fp32 mel tensor written and read back.
 #include "mia_device.h"
 #include "mia_internal.h"
 
@@ -45,17 +50,46 @@ __device__ __forceinline__ float vsample(const float* __restrict__ x, int64_t L,
   return (v >= 0 && v < L) ? x[v] : 0.0f;
 }
 
+// out element (b, f, m) lives at out[b*clip_stride + (f+row_off)*row_stride + m*col_stride]
+template <typename OutT>
+__device__ __forceinline__ void store_out(void* out, size_t idx, float v);
+template <>
+__device__ __forceinline__ void store_out<float>(void* out, size_t idx, float v) { ((float*)out)[idx] = v; }
+template <>
+__device__ __forceinline__ void store_out<BF16>(void* out, size_t idx, float v) { ((uint16_t*)out)[idx] = BF16::from_f32(v); }
+template <>
+__device__ __forceinline__ void store_out<F16>(void* out, size_t idx, float v) { ((uint16_t*)out)[idx] = F16::from_f32(v); }
+
+template <typename OutT>
+__device__ __forceinline__ float load_out(const void* out, size_t idx);
+template <>
+__device__ __forceinline__ float load_out<float>(const void* out, size_t idx) { return ((const float*)out)[idx]; }
+template <>
+__device__ __forceinline__ float load_out<BF16>(const void* out, size_t idx) { return BF16::to_f32(((const uint16_t*)out)[idx]); }
+template <>
+__device__ __forceinline__ float load_out<F16>(const void* out, size_t idx) { return F16::to_f32(((const uint16_t*)out)[idx]); }
+
+template <typename OutT>
+__device__ __forceinline__ float round_out(float v) { return v; }
+template <>
+__device__ __forceinline__ float round_out<BF16>(float v) { return BF16::to_f32(BF16::from_f32(v)); }
+template <>
+__device__ __forceinline__ float round_out<F16>(float v) { return F16::to_f32(F16::from_f32(v)); }
+
+// DIRECT: store (v + 4) / 4 as OutT at out[b*clip_stride + (f+row_off)*row_stride + m] and the block's minimum v in tmp[b*gridDim.x + block]
+template <typename OutT, bool DIRECT>
 __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ pcm, const ClipInfo* __restrict__ clips,
                                                     int64_t pad_right, int64_t n_out, int n_mels,
                                                     const float* __restrict__ window, const float* __restrict__ twiddle,
                                                     const float* __restrict__ fb_w, const int* __restrict__ fb_meta,
-                                                    int fb_nnz, float* __restrict__ tmp, int* __restrict__ gmax) {
+                                                    int fb_nnz, float* __restrict__ tmp, int* __restrict__ gmax,
+                                                    void* __restrict__ out, int64_t clip_stride, int64_t row_stride, int64_t row_off) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* F = reinterpret_cast<float*>(smem_raw);            // [FB][FSTR]
   float* P = F + FB * FSTR;                                 // [FB][PSTR]
   float* W = P + FB * PSTR;                                 // [MAX_NNZ]
   int* META = reinterpret_cast<int*>(W + MAX_NNZ);          // [MAX_MELS][3]
-  float* RED = reinterpret_cast<float*>(META + MAX_MELS * 3);  // [4]
+  float* RED = reinterpret_cast<float*>(META + MAX_MELS * 3);  // [8]: per-wave max, per-wave min
 
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
@@ -105,7 +139,7 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ pc
   __syncthreads();
 
   // ---- mel filterbank (sparse rows, ascending bin order) + log10 --------------------------------
-  float vmax = -INFINITY;
+  float vmax = -INFINITY, vmin = INFINITY;
   for (int idx = tid; idx < FB * n_mels; idx += 256) {
     const int i = idx / n_mels, m = idx - i * n_mels;
     const int64_t f = f0 + i;
@@ -116,14 +150,48 @@ __global__ __launch_bounds__(256) void logmel_pass1(const float* __restrict__ pc
     for (int c = 0; c < cnt; ++c) acc = fmaf(p[c], W[off + c], acc);
     const float v = log10f(fmaxf(acc, 1e-10f));
     vmax = fmaxf(vmax, v);
-    if (f < n_out) tmp[((size_t)b * n_out + f) * n_mels + m] = v;
+    if (f < n_out) {
+      if (DIRECT) { vmin = fminf(vmin, v); store_out<OutT>(out, (size_t)(b * clip_stride + (f + row_off) * row_stride + m), (v + 4.0f) / 4.0f); }
+      else tmp[((size_t)b * n_out + f) * n_mels + m] = v;
+    }
   }
   vmax = wave_max(vmax);
-  if (lane == 0) RED[wave] = vmax;
+  if (DIRECT) vmin = -wave_max(-vmin);
+  if (lane == 0) { RED[wave] = vmax; if (DIRECT) RED[4 + wave] = vmin; }
   __syncthreads();
   if (tid == 0) {
     const float m4 = fmaxf(fmaxf(RED[0], RED[1]), fmaxf(RED[2], RED[3]));
     atomicMax(&gmax[b], float_to_ordered(m4));
+    if (DIRECT) tmp[(size_t)b * gridDim.x + blockIdx.x] = fminf(fminf(RED[4], RED[5]), fminf(RED[6], RED[7]));
+  }
+}
+
+// The clamp that is left after a DIRECT pass 1 (see the file header): block (x, b) owns output frames [32 x, 32 x + 32) of clip b.
+template <typename OutT>
+__global__ __launch_bounds__(256) void logmel_clampfix(const float* __restrict__ blkmin, int nblk1, const int* __restrict__ gmax,
+                                                       const ClipInfo* __restrict__ clips, int64_t pad_right, int64_t n_out, int n_mels,
+                                                       void* __restrict__ out, int64_t clip_stride, int64_t row_stride, int64_t row_off) {
+  const int b = blockIdx.y;
+  const int64_t L = clips[b].len;
+  const int64_t F_total = (L + pad_right) / HOP;
+  int64_t F_content = (L + NFFT / 2 + HOP - 1) / HOP;
+  if (F_content > F_total) F_content = F_total;
+  const int64_t f0 = (int64_t)blockIdx.x * FB;
+  const float floor_v = ordered_to_float(gmax[b]) - 8.0f;
+  const bool all_content = f0 + FB <= F_content && f0 + FB <= n_out;
+  const bool need_clamp = f0 < F_content && blkmin[(size_t)b * nblk1 + blockIdx.x] < floor_v;
+  if (all_content && !need_clamp) return;                                   // the common case: nothing to do for this block
+  const float floor_o = (floor_v + 4.0f) / 4.0f;                            // the clamp in output units (rounded by store_out like any value)
+  const float floor_r = round_out<OutT>(floor_o);                           // ... and as the output type holds it
+  const float pad_o = (fmaxf(-10.0f, floor_v) + 4.0f) / 4.0f;               // frames whose window holds no audio: log10(1e-10) = -10
+  for (int idx = threadIdx.x; idx < FB * n_mels; idx += 256) {
+    const int i = idx / n_mels, m = idx - i * n_mels;
+    const int64_t f = f0 + i;
+    if (f >= n_out) continue;
+    const size_t o = (size_t)(b * clip_stride + (f + row_off) * row_stride + m);
+    if (f >= F_total) store_out<OutT>(out, o, 0.0f);                        // padOrTrimMel pads with 0.0 (WhisperSTT.swift:624-635)
+    else if (f >= F_content) store_out<OutT>(out, o, pad_o);
+    else if (need_clamp && load_out<OutT>(out, o) < floor_r) store_out<OutT>(out, o, floor_o);   // max in the OUTPUT type
   }
 }
 
@@ -131,16 +199,6 @@ __global__ void logmel_init(int* gmax, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) gmax[i] = float_to_ordered(-10.0f);   // log10(1e-10): lower bound of every value
 }
-
-// out element (b, f, m) lives at out[b*clip_stride + (f+row_off)*row_stride + m*col_stride]
-template <typename OutT>
-__device__ __forceinline__ void store_out(void* out, size_t idx, float v);
-template <>
-__device__ __forceinline__ void store_out<float>(void* out, size_t idx, float v) { ((float*)out)[idx] = v; }
-template <>
-__device__ __forceinline__ void store_out<BF16>(void* out, size_t idx, float v) { ((uint16_t*)out)[idx] = BF16::from_f32(v); }
-template <>
-__device__ __forceinline__ void store_out<F16>(void* out, size_t idx, float v) { ((uint16_t*)out)[idx] = F16::from_f32(v); }
 
 template <typename OutT, bool CHANNEL_MAJOR>
 __global__ __launch_bounds__(256) void logmel_pass2(const float* __restrict__ tmp, const int* __restrict__ gmax,
@@ -252,7 +310,7 @@ int get_tables(mia_ctx* ctx, int n_mels, int window_kind, mia_ctx::MelTables** o
   return MIA_OK;
 }
 
-constexpr size_t PASS1_LDS = (size_t)(FB * FSTR + FB * PSTR + MAX_NNZ) * 4 + MAX_MELS * 3 * 4 + 16;
+constexpr size_t PASS1_LDS = (size_t)(FB * FSTR + FB * PSTR + MAX_NNZ) * 4 + MAX_MELS * 3 * 4 + 32;   // ... + RED[8]
 
 }  // namespace
 
@@ -302,32 +360,53 @@ int mia_logmel_device(mia_ctx* ctx, const float* pcm_dev, const int64_t* offs_ho
   for (int b = 0; b < B; ++b) alg_bytes += (double)clips[b].len * 4.0 + (double)n_out * n_mels * mia_dtype_size(out_dtype);
   const int prof_rec = mia_prof_begin(ctx, MIA_PROF_LOGMEL, alg_bytes);
   hipLaunchKernelGGL(logmel_init, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, d_gmax, B);
+  // 86 KB of dynamic LDS: above the 64 KB default cap.  Several contexts (bench.py's replica threads) reach this concurrently.
+  static std::once_flag lds_attr_once;
+  static hipError_t lds_attr_rc = hipSuccess;
+  std::call_once(lds_attr_once, [] {
+    const void* fns[4] = {(const void*)logmel_pass1<float, false>, (const void*)logmel_pass1<float, true>, (const void*)logmel_pass1<F16, true>,
+                          (const void*)logmel_pass1<BF16, true>};
+    for (const void* f : fns) { const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS1_LDS); if (e != hipSuccess) lds_attr_rc = e; }
+  });
+  MIA_HIP(ctx, lds_attr_rc);
+  const unsigned nblk1 = (unsigned)((max_content + FB - 1) / FB);
+  // time-major outputs with unit column stride take the single-pass form (file header); the channel-major (S3) layout keeps the fp32
+  // intermediate: its transposed stores are coalesced only along frames, which pass 2 walks
+  const bool direct = !channel_major && col_stride == 1;
+#define LAUNCH1(T, D)                                                                                                        \
+  hipLaunchKernelGGL((logmel_pass1<T, D>), dim3(nblk1, (unsigned)B), dim3(256), PASS1_LDS, ctx->stream, pcm_dev, d_clips, pad_right, n_out, \
+                     n_mels, tb->window, tb->twiddle, tb->fb_w, tb->fb_meta, tb->fb_nnz, d_tmp, d_gmax, out_dev, clip_stride, row_stride, row_off)
   if (max_content > 0) {
-    // 86 KB of dynamic LDS: above the 64 KB default cap.  Several contexts (bench.py's replica threads) reach this concurrently.
-    static std::once_flag lds_attr_once;
-    static hipError_t lds_attr_rc = hipSuccess;
-    std::call_once(lds_attr_once, [] { lds_attr_rc = hipFuncSetAttribute((const void*)logmel_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PASS1_LDS); });
-    MIA_HIP(ctx, lds_attr_rc);
-    dim3 grid((unsigned)((max_content + FB - 1) / FB), (unsigned)B);
-    hipLaunchKernelGGL(logmel_pass1, grid, dim3(256), PASS1_LDS, ctx->stream, pcm_dev, d_clips, pad_right, n_out, n_mels,
-                       tb->window, tb->twiddle, tb->fb_w, tb->fb_meta, tb->fb_nnz, d_tmp, d_gmax);
+    if (!direct) LAUNCH1(float, false);
+    else if (out_dtype == MIA_F32) LAUNCH1(float, true);
+    else if (out_dtype == MIA_F16) LAUNCH1(F16, true);
+    else LAUNCH1(BF16, true);
   }
-  const int64_t total = n_out * n_mels;
-  unsigned gx = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
-  dim3 grid2(gx, (unsigned)B);
-#define LAUNCH2(T, CM)                                                                                               \
-  hipLaunchKernelGGL((logmel_pass2<T, CM>), grid2, dim3(256), 0, ctx->stream, d_tmp, d_gmax, d_clips, pad_right, n_out, \
-                     n_mels, out_dev, clip_stride, row_stride, col_stride, row_off)
-  if (channel_major) {
-    if (out_dtype == MIA_F32) LAUNCH2(float, true);
-    else if (out_dtype == MIA_F16) LAUNCH2(F16, true);
-    else LAUNCH2(BF16, true);
+#undef LAUNCH1
+  if (direct) {
+    const dim3 gridf((unsigned)((n_out + FB - 1) / FB), (unsigned)B);
+#define LAUNCHF(T) hipLaunchKernelGGL((logmel_clampfix<T>), gridf, dim3(256), 0, ctx->stream, d_tmp, (int)nblk1, d_gmax, d_clips, pad_right, n_out, n_mels, \
+                                      out_dev, clip_stride, row_stride, row_off)
+    if (out_dtype == MIA_F32) LAUNCHF(float); else if (out_dtype == MIA_F16) LAUNCHF(F16); else LAUNCHF(BF16);
+#undef LAUNCHF
   } else {
-    if (out_dtype == MIA_F32) LAUNCH2(float, false);
-    else if (out_dtype == MIA_F16) LAUNCH2(F16, false);
-    else LAUNCH2(BF16, false);
-  }
+    const int64_t total = n_out * n_mels;
+    unsigned gx = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+    dim3 grid2(gx, (unsigned)B);
+#define LAUNCH2(T, CM)                                                                                               \
+    hipLaunchKernelGGL((logmel_pass2<T, CM>), grid2, dim3(256), 0, ctx->stream, d_tmp, d_gmax, d_clips, pad_right, n_out, \
+                       n_mels, out_dev, clip_stride, row_stride, col_stride, row_off)
+    if (channel_major) {
+      if (out_dtype == MIA_F32) LAUNCH2(float, true);
+      else if (out_dtype == MIA_F16) LAUNCH2(F16, true);
+      else LAUNCH2(BF16, true);
+    } else {
+      if (out_dtype == MIA_F32) LAUNCH2(float, false);
+      else if (out_dtype == MIA_F16) LAUNCH2(F16, false);
+      else LAUNCH2(BF16, false);
+    }
 #undef LAUNCH2
+  }
   mia_prof_end(ctx, prof_rec);
   MIA_HIP(ctx, hipGetLastError());
   // clips[] lives on the host stack of this call: the async H2D copy above must have consumed it.
