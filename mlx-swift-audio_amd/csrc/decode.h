@@ -2,7 +2,7 @@
 #pragma once
 #include "whisper.h"
 
-enum { SK_OUT16 = 0, SK_OUTF32 = 1, SK_PARTIAL = 2, SK_QKV = 3, SK_SWIGLU = 4 };
+enum { SK_OUT16 = 0, SK_OUTF32 = 1, SK_PARTIAL = 2, SK_QKV = 3, SK_SWIGLU = 4, SK_RESID = 5 };
 
 // ---- MFMA-fragment order (the Whisper decode step's GEMM operands) -------------------------------------------------------------
 // v_mfma_f32_16x16x32 takes, per lane (r = lane & 15, c = lane >> 4), the 8 consecutive K-values 8c..8c+7 of row r.  Stored row-major,
@@ -28,6 +28,14 @@ struct SkinnyArgs {
   int M, N, K, S, act, D, H, n_ctx;
   int out_frag = 0;                      // fragment-order kernels, OUT16: write `out` in activation fragment order (row length N)
   int w_frag = 0;                        // row-major-activation kernels (the LM step): W is in weight fragment order
+  // ---- RMSNorm carried across the GEMM chain of the LM step (no separate reduce + norm launch):
+  // SK_RESID (needs S == 1): xres[m][n] += acc (+ bias) in place (the fp32 residual stream, row stride N); out[m][n] (16-bit, row stride
+  //   ldo) = (x_new * nw[n]) rounded -- the NEXT block's activation, not yet divided by its rms; ss_out[tile][m] = sum of x_new^2 over the
+  //   tile's 16 columns (tile = n / 16), one value per (tile, row), written by exactly one lane: a fixed-order partial sum.
+  // consumers of such an activation (any mode) pass ss_in / ss_tiles / ss_dim / eps: the accumulator of row m is multiplied by
+  //   rstd[m] = rsqrt(sum_t ss_in[t][m] / ss_dim + eps) before bias and activation -- linear, so it commutes with the contraction.
+  float* xres = nullptr; const float* nw = nullptr; float* ss_out = nullptr;
+  const float* ss_in = nullptr; int ss_tiles = 0; int ss_dim = 0; float eps = 0.f;
 };
 
 int dec_launch_embed_ln(mia_whisper* w, const LNW& ln, hipStream_t s);

@@ -168,6 +168,20 @@ __device__ __forceinline__ bool skinny_wave_reduce(f32x4 (&acc)[NT][2], int wave
   return true;
 }
 
+// rstd of the (up to 32) rows of this workgroup from the producer's per-tile partial sums of squares (SkinnyArgs::ss_in): computed by
+// wave 0 at the START of the kernel -- its loads ride under the weight stream -- into LDS; the epilogue (wave 0 again, behind the
+// reduction barrier when the workgroup has one) reads rs[row].  Lanes take tiles t = lane, lane + 64, ...; fixed-order sums.
+__device__ __forceinline__ void skinny_rstd_prepare(const SkinnyArgs& a, float* rs, int m0, int wave, int lane) {
+  if (!a.ss_in || wave != 0) return;
+  const int rows = a.M - m0 < 32 ? a.M - m0 : 32;
+  for (int j = 0; j < rows; ++j) {
+    float v = 0.f;
+    for (int t = lane; t < a.ss_tiles; t += 64) v += a.ss_in[(int64_t)t * a.M + m0 + j];
+    v = wave_sum(v);
+    if (lane == 0) rs[j] = rsqrtf(v / (float)a.ss_dim + a.eps);
+  }
+}
+
 // lane holds C[m = m0 + mt*16 + r][n = n0 + 16t + 4c + j]
 template <typename T, int MODE, int NT>
 __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane) {
@@ -291,11 +305,46 @@ __device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32
 // Row-major-activation kernels (the LM step): the same vector stores.  SK_SWIGLU: a lane's 4 consecutive columns are (gate, up, gate, up)
 // -> two outputs, one 4-byte store; SK_QKV keeps the scalar form (the Whisper step, its only user, runs the fragment-order kernels).
 template <typename T, int MODE, int NT>
-__device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane) {
-  if constexpr (MODE == SK_QKV) {
+__device__ __forceinline__ void skinny_store(const SkinnyArgs& a, f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane, const float* rs = nullptr) {
+  const int r = lane & 15, c = lane >> 4;
+  if (a.ss_in && rs) {       // the activation was stored un-normalised (SK_RESID producer): scale every row by its rstd first
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int mr = mt * 16 + r;
+      const float sc = m0 + mr < a.M ? rs[mr] : 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][mt][j] *= sc;
+    }
+  }
+  if constexpr (MODE == SK_RESID) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + 16 * t + 4 * c;                 // host-checked: N % 16 == 0
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(a.nw + n);
+      f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + mt * 16 + r;
+        float q = 0.f;
+        if (m < a.M) {
+          float* xp = a.xres + (int64_t)m * a.N + n;
+          f32x4 x = *reinterpret_cast<const f32x4*>(xp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { x[j] += acc[t][mt][j] + bv[j]; q += x[j] * x[j]; }
+          *reinterpret_cast<f32x4*>(xp) = x;
+          *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + (int64_t)m * a.ldo + n) = (u32x2){pack2<T>(x[0] * wv[0], x[1] * wv[1]), pack2<T>(x[2] * wv[2], x[3] * wv[3])};
+        }
+        // the tile's 16 columns live in the 4 lanes r, r + 16, r + 32, r + 48: fixed-order sum (c = 0, 1, 2, 3)
+        const float q1 = __shfl(q, r + 16, 64), q2 = __shfl(q, r + 32, 64), q3 = __shfl(q, r + 48, 64);
+        if (c == 0 && m < a.M) a.ss_out[(int64_t)((n0 >> 4) + t) * a.M + m] = ((q + q1) + q2) + q3;
+      }
+    }
+  } else if constexpr (MODE == SK_QKV) {
     skinny_epilogue<T, MODE, NT>(a, acc, n0, m0, split, lane);
   } else if constexpr (MODE == SK_SWIGLU) {
-    const int r = lane & 15, c = lane >> 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int n = n0 + 16 * t + 4 * c;
@@ -327,6 +376,7 @@ __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, const f32x4 (&
 
 template <typename T, int MODE, int NT, int KB, int NW>
 __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
+  __shared__ float rs[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * (16 * NT);
   const int split = blockIdx.y;
@@ -411,6 +461,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
     load_batch(b0, 0);
     if (nb > 1) load_batch(b1, KSTEP);
     if (nb > 2) load_batch(b2, 2 * KSTEP);
+    skinny_rstd_prepare(a, rs, m0, wave, lane);      // behind the first three batches of loads: its own loads ride under the weight stream
     for (int i = 0; i < nb; i += 4) {
       if (i + 3 < nb) load_batch(b3, (i + 3) * KSTEP);
       mma_batch(b0);
@@ -424,7 +475,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
       if (i + 6 < nb) load_batch(b2, (i + 6) * KSTEP);
       mma_batch(b3);
     }
-  }
+  } else skinny_rstd_prepare(a, rs, m0, wave, lane);
   if (early_tail) {
 #pragma unroll
     for (int u = 0; u < KB; ++u)
@@ -448,7 +499,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
     }
   }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_store<T, MODE, NT>(a, acc, n0, m0, split, lane);
+  skinny_store<T, MODE, NT>(a, acc, n0, m0, split, lane, rs);
 }
 
 // The same GEMM for a SHORT K-slice per wave (exactly NSTEP K-steps of 32, host-checked: K == S * NW * 32 * NSTEP): every operand
@@ -458,6 +509,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
 // L2 / MALL.  Same K order per wave and same wave-order reduction as dec_skinny_gemm: results are bit-identical to it.
 template <typename T, int MODE, int NT, int NSTEP, int NW>
 __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
+  __shared__ float rs[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * (16 * NT);
   const int split = blockIdx.y;
@@ -494,6 +546,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
     if (av1) fa1[u] = *reinterpret_cast<const s16x8*>(ap1 + 32 * u);
   }
   __builtin_amdgcn_sched_barrier(0);   // keep every load ahead of the first MFMA (the scheduler would otherwise trade them for registers)
+  skinny_rstd_prepare(a, rs, m0, wave, lane);
   f32x4 acc[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -505,7 +558,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
       acc[n][1] = T::mfma16(fw[u][n], fa1[u], acc[n][1]);
     }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_store<T, MODE, NT>(a, acc, n0, m0, split, lane);
+  skinny_store<T, MODE, NT>(a, acc, n0, m0, split, lane, rs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -688,26 +741,43 @@ template <> struct QMagic<F16> { static constexpr uint32_t pair = 0x64006400u; s
 // Epilogue of the transposed accumulator layout (activations are the MFMA's row operand here): lane (r, c) holds
 // C[m = m0 + 16 mt + 4 c + i][n = n0 + 16 t + r], i = 0..3 -- one output column per lane, so scale / offset are per-lane scalars.
 template <typename T, int MODE, int NT>
-__device__ __forceinline__ void skinny_store_tr(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane) {
+__device__ __forceinline__ void skinny_store_tr(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int split, int lane, const float* rs) {
   const int r = lane & 15, c = lane >> 4;
+  const bool scaled = a.ss_in != nullptr;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int n = n0 + 16 * t + r;
     const bool nv = n < a.N;
     const float bs = (MODE != SK_PARTIAL && a.bias && nv) ? a.bias[n] : 0.f;
+    const float wn = (MODE == SK_RESID && nv) ? a.nw[n] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 16 * mt + 4 * c + i;
-        float v = acc[t][mt][i] + bs;
+        const int mr = 16 * mt + 4 * c + i, m = m0 + mr;
+        const bool mv = m < a.M;
+        const float raw = scaled ? acc[t][mt][i] * (mv ? rs[mr] : 0.f) : acc[t][mt][i];
+        float v = raw + bs;
         if (MODE == SK_SWIGLU) {                 // interleaved rows: even column = gate, odd column = up (the neighbouring lane)
           const float u = dpp_f32<0xB1>(v);      // quad_perm [1, 0, 3, 2]: every lane executes the exchange
-          if (nv && m < a.M && !(r & 1)) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + (n >> 1)] = T::from_f32((v / (1.0f + __expf(-v))) * u);
+          if (nv && mv && !(r & 1)) reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + (n >> 1)] = T::from_f32((v / (1.0f + __expf(-v))) * u);
           continue;
         }
-        if (!nv || m >= a.M) continue;
-        if (MODE == SK_PARTIAL) reinterpret_cast<float*>(a.out)[((int64_t)split * a.M + m) * a.N + n] = acc[t][mt][i];
+        if (MODE == SK_RESID) {                  // x += acc; next activation = x * norm weight; the tile's sum of squares (16 lanes of a DPP row)
+          float x = 0.f;
+          if (nv && mv) {
+            float* xp = a.xres + (int64_t)m * a.N + n;
+            x = *xp + v;
+            *xp = x;
+            reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + n] = T::from_f32(x * wn);
+          }
+          float q = x * x;
+          q += dpp_f32<0xB1>(q); q += dpp_f32<0x4E>(q); q += dpp_f32<0x141>(q); q += dpp_f32<0x140>(q);     // fixed butterfly: every lane of the row holds the sum
+          if (r == 0 && mv) a.ss_out[(int64_t)((n0 >> 4) + t) * a.M + m] = q;
+          continue;
+        }
+        if (!nv || !mv) continue;
+        if (MODE == SK_PARTIAL) reinterpret_cast<float*>(a.out)[((int64_t)split * a.M + m) * a.N + n] = raw;
         else if (MODE == SK_OUTF32) reinterpret_cast<float*>(a.out)[(int64_t)m * a.ldo + n] = v;
         else reinterpret_cast<uint16_t*>(a.out)[(int64_t)m * a.ldo + n] = T::from_f32(v);
       }
@@ -719,6 +789,7 @@ __device__ __forceinline__ void skinny_store_tr(const SkinnyArgs& a, const f32x4
 // NP: nibble planes per code (1 = 4-bit, 2 = 8-bit)
 template <typename T, int MODE, int NT, int NW, bool M16, int NP>
 __global__ __launch_bounds__(64 * NW) void skinny_gemm_qi(SkinnyArgs a, QFrag q) {
+  __shared__ float rs[32];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile0 = blockIdx.x * NT;
@@ -801,6 +872,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_qi(SkinnyArgs a, QFrag q)
   Blk k0, k1, k2;
   if (bc > 0) load_blk(k0, b0);
   if (bc > 1) load_blk(k1, b0 + 1);
+  skinny_rstd_prepare(a, rs, m0, wave, lane);        // behind the first two blocks of loads: its own loads ride under the weight stream
   for (int i = 0; i < bc; i += 3) {
     if (i + 2 < bc) load_blk(k2, b0 + i + 2);
     mma_blk(k0);
@@ -812,7 +884,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_qi(SkinnyArgs a, QFrag q)
     mma_blk(k2);
   }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_store_tr<T, MODE, NT>(a, acc, n0, m0, split, lane);
+  skinny_store_tr<T, MODE, NT>(a, acc, n0, m0, split, lane, rs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1445,6 +1517,7 @@ static void skinny_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
     case SK_OUT16: if (skinny_flat_try<T, SK_OUT16>(a, s)) return; break;
     case SK_PARTIAL: if (skinny_flat_try<T, SK_PARTIAL>(a, s)) return; break;
     case SK_SWIGLU: if (skinny_flat_try<T, SK_SWIGLU>(a, s)) return; break;
+    case SK_RESID: break;    // N / 16 workgroups only: always the ring kernel with K over 4 / 8 / 16 waves (below)
     default: if (skinny_flat_try<T, SK_QKV>(a, s)) return; break;
   }
   if (mode == SK_OUTF32) {   // the vocabulary-wide logits GEMM: 64 columns per wave
@@ -1464,6 +1537,12 @@ static void skinny_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
     case SK_OUT16: SK_LAUNCH(SK_OUT16); break;
     case SK_PARTIAL: SK_LAUNCH(SK_PARTIAL); break;
     case SK_SWIGLU: SK_LAUNCH(SK_SWIGLU); break;
+    case SK_RESID:
+      // no cross-workgroup split here (the epilogue owns the residual row slice): N / 16 workgroups only, so K goes over 8 waves
+      if (a.K % 1024 == 0 && a.K >= 8192) hipLaunchKernelGGL((dec_skinny_gemm<T, SK_RESID, 1, 2, 16>), grid, dim3(1024), 0, s, a);
+      else if (a.K % 256 == 0 && a.K >= 2048) hipLaunchKernelGGL((dec_skinny_gemm<T, SK_RESID, 1, 2, 8>), grid, dim3(512), 0, s, a);
+      else SK_LAUNCH(SK_RESID);
+      break;
     default: SK_LAUNCH(SK_QKV); break;
   }
 #undef SK_LAUNCH
@@ -1472,6 +1551,8 @@ static void skinny_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
 int skinny_gemm_launch(const SkinnyArgs& a, int mode, int dtype, hipStream_t s) {
   if (a.K % (32 * a.S) != 0 || a.lda % 8 != 0) return -1;
   if (mode == SK_SWIGLU && (a.N & 3)) return -1;
+  if (mode == SK_RESID && (a.S != 1 || (a.N & 15) || (a.ldo & 3) || !a.xres || !a.nw || !a.ss_out)) return -1;
+  if (a.ss_in && (a.ss_tiles <= 0 || a.ss_dim <= 0)) return -1;
   if (dtype == MIA_F16) skinny_launch_t<F16>(a, mode, s); else skinny_launch_t<BF16>(a, mode, s);
   return 0;
 }
@@ -1499,6 +1580,11 @@ static void skinny_qi_launch_m(const SkinnyArgs& a, const QFrag& q, int mode, hi
     case SK_OUTF32: QI_LAUNCH(SK_OUTF32); break;
     case SK_OUT16: QI_LAUNCH(SK_OUT16); break;
     case SK_SWIGLU: QI_LAUNCH(SK_SWIGLU); break;
+    case SK_RESID:
+      if (!nt4 && per_split % 16 == 0 && per_split >= 64) QI_GO(SK_RESID, 1, 16);            // N / 16 workgroups only: K over 8 or 16 waves
+      else if (!nt4 && per_split % 8 == 0) QI_GO(SK_RESID, 1, 8);
+      else QI_LAUNCH(SK_RESID);
+      break;
     default: QI_LAUNCH(SK_PARTIAL); break;
   }
 #undef QI_LAUNCH
@@ -1515,8 +1601,10 @@ static void skinny_qi_launch_t(const SkinnyArgs& a, const QFrag& q, int bits, in
 int skinny_gemm_q_launch(const SkinnyArgs& a, const uint32_t* wfrag, const float* stfrag, int bits, int mode, int dtype, hipStream_t s) {
   if (a.K % (128 * a.S) != 0 || a.lda % 8 != 0 || !wfrag || !stfrag) return -1;
   if (bits != 4 && bits != 8) return -1;
-  if (mode != SK_OUT16 && mode != SK_OUTF32 && mode != SK_PARTIAL && mode != SK_SWIGLU) return -1;
+  if (mode != SK_OUT16 && mode != SK_OUTF32 && mode != SK_PARTIAL && mode != SK_SWIGLU && mode != SK_RESID) return -1;
   if (mode == SK_SWIGLU && (a.N & 3)) return -1;
+  if (mode == SK_RESID && (a.S != 1 || (a.N & 15) || !a.xres || !a.nw || !a.ss_out)) return -1;
+  if (a.ss_in && (a.ss_tiles <= 0 || a.ss_dim <= 0)) return -1;
   const QFrag q{wfrag, stfrag};
   if (dtype == MIA_F16) skinny_qi_launch_t<F16>(a, q, bits, mode, s); else skinny_qi_launch_t<BF16>(a, q, bits, mode, s);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -64,6 +64,7 @@ struct mia_lm {
   void* k_cache = nullptr; void* v_cache = nullptr;   // [L][Hkv][max_ctx][dh]
   float* x = nullptr; void* h = nullptr; float* qkv_part = nullptr; void* q = nullptr; void* att = nullptr; void* act = nullptr;
   float* partial = nullptr; float* logits = nullptr;
+  float* ss = nullptr;          // [2][hidden / 16][B]: per-tile partial sums of squares of the residual stream (SK_RESID producers)
   int32_t* tokens = nullptr;    // [max_ctx] full sequence
   int32_t* hist = nullptr;      // [64] repetition window (ring, oldest first)
   float* uniforms = nullptr;    // [max_ctx]
@@ -973,9 +974,19 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
   const int D = c.hidden, dh = c.head_dim, Nq = c.n_heads * dh, Nk = c.n_kv_heads * dh, Nqkv = Nq + 2 * Nk;
   const bool f16 = m->dtype == MIA_F16;
   // nb sequences = nb rows of every skinny GEMM: the weights are still read once per step
+  // RMSNorm rides on the GEMMs (decode.h, SkinnyArgs): the two residual-writing projections (o, down) add into x, emit the next block's
+  // activation x * norm weight (16 bit) and per-tile sums of squares; the GEMM that consumes it scales its accumulators by rstd.  Two
+  // launches less per layer than "GEMM -> split-K partials -> reduce + norm kernel" (5.1 us each on Orpheus-3B, 56 per token).
+  const bool fused_norm = (D % 16) == 0;
+  const int ss_tiles = D / 16;
+  float* ss_o = m->ss;                                   // written by o-proj, read by gate|up
+  float* ss_d = m->ss + (size_t)ss_tiles * m->B_cap;     // written by down-proj, read by the next q|k|v (or the head)
+  struct Norm { const float* ss = nullptr; };            // consumer side: which partial sums (null = activation already normalised)
   auto skinny = [&](const void* A, int64_t lda, const void* W, const void* Wf, const float* bias, void* out, int64_t ldo, int N, int K, int S, int mode,
-                    const Q4W* qw = nullptr) {
+                    const Q4W* qw = nullptr, const float* ss_in = nullptr, const float* nw = nullptr, float* ss_out = nullptr) {
     SkinnyArgs a{(const uint16_t*)A, lda, (const uint16_t*)W, bias, out, ldo, nullptr, nullptr, nullptr, nb, N, K, S, MIA_ACT_NONE, 0, 0, 0};
+    if (ss_in) { a.ss_in = ss_in; a.ss_tiles = ss_tiles; a.ss_dim = D; a.eps = c.rms_eps; }
+    if (mode == SK_RESID) { a.xres = m->x; a.nw = nw; a.ss_out = ss_out; }
     if (m->q4 && qw && qw->wfrag) return skinny_gemm_q_launch(a, qw->wfrag, qw->stfrag, m->q_bits, mode, m->dtype, s);
     if (Wf) { a.W = (const uint16_t*)Wf; a.w_frag = 1; }      // same K order and partition as the row-major form: identical results
     return skinny_gemm_launch(a, mode, m->dtype, s);
@@ -987,17 +998,27 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
     const LmLayer& L = m->layers[l];
     uint16_t* kc = (uint16_t*)m->k_cache + (size_t)l * layer_stride;
     uint16_t* vc = (uint16_t*)m->v_cache + (size_t)l * layer_stride;
+    const float* next_norm = l + 1 < c.n_layers ? m->layers[l + 1].in_norm : m->final_norm;
+    if (fused_norm) {
+      // layer 0 reads the embedding kernel's (normalised) h; later layers the previous down-proj's x * norm weight + its sums of squares
+      if (skinny(m->h, D, L.wqkv, L.wqkv_f, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL, &L.q_qkv, l > 0 ? ss_d : nullptr)) return -1;
+      lm_launch_attention(m, true, nb, nullptr, kc, vc, m->att, nullptr, m->qkv_part, m->S_qkv, L.bqkv);      // RoPE + cache row + attention
+      if (skinny(m->att, Nq, L.wo, L.wo_f, nullptr, m->h, D, D, Nq, 1, SK_RESID, &L.q_o, nullptr, L.post_norm, ss_o)) return -1;
+      if (skinny(m->h, D, L.wgu, L.wgu_f, nullptr, m->act, c.inter, 2 * c.inter, D, 1, SK_SWIGLU, &L.q_gu, ss_o)) return -1;
+      if (skinny(m->act, c.inter, L.wdown, L.wdown_f, nullptr, m->h, D, D, c.inter, 1, SK_RESID, &L.q_down, nullptr, next_norm, ss_d)) return -1;
+      continue;
+    }
     if (skinny(m->h, D, L.wqkv, L.wqkv_f, nullptr, m->qkv_part, 0, Nqkv, D, m->S_qkv, SK_PARTIAL, &L.q_qkv)) return -1;
     lm_launch_attention(m, true, nb, nullptr, kc, vc, m->att, nullptr, m->qkv_part, m->S_qkv, L.bqkv);      // RoPE + cache row + attention
     if (skinny(m->att, Nq, L.wo, L.wo_f, nullptr, m->partial, 0, D, Nq, m->S_o, SK_PARTIAL, &L.q_o)) return -1;
     LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_o, L.post_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
     if (skinny(m->h, D, L.wgu, L.wgu_f, nullptr, m->act, c.inter, 2 * c.inter, D, 1, SK_SWIGLU, &L.q_gu)) return -1;
     if (skinny(m->act, c.inter, L.wdown, L.wdown_f, nullptr, m->partial, 0, D, c.inter, m->S_down, SK_PARTIAL, &L.q_down)) return -1;
-    LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_down, l + 1 < c.n_layers ? m->layers[l + 1].in_norm : m->final_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
+    LAUNCH_T(lm_reduce_norm, dim3(nb), dim3(256), 0, m->partial, m->S_down, next_norm, m->x, (uint16_t*)m->h, D, c.rms_eps, nb);
   }
 #undef LAUNCH_T
   const int HV = m->head_vocab > 0 ? m->head_vocab : c.vocab;
-  if (skinny(m->h, D, m->lm_head, m->lm_head_f, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32, &m->q_head)) return -1;
+  if (skinny(m->h, D, m->lm_head, m->lm_head_f, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32, &m->q_head, fused_norm && c.n_layers > 0 ? ss_d : nullptr)) return -1;
   if (ras) hipLaunchKernelGGL(lm_sample_ras, dim3(nb), dim3(1024), 0, s, m->logits, HV, m->tokens, m->out_tokens, m->uniforms, m->state, *ras, c.max_ctx);
   else if (sampling) { if (lm_sample_launch(s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx, nb)) return -1; }
   else hipLaunchKernelGGL(lm_advance, dim3(nb), dim3(1), 0, s, m->state);
@@ -1138,6 +1159,7 @@ int lm_alloc_state(mia_lm* m, int B) {
   m->k_cache = dev(kv); m->v_cache = dev(kv);
   m->x = (float*)dev((size_t)B * D * 4); m->h = dev((size_t)B * D * 2);
   m->qkv_part = (float*)dev((size_t)4 * B * (Nq + 2 * Nk) * 4); m->q = dev((size_t)B * Nq * 2); m->att = dev((size_t)B * Nq * 2); m->act = dev((size_t)B * c.inter * 2);
+  m->ss = (float*)dev((size_t)2 * ((D + 15) / 16) * B * 4);
   m->partial = (float*)dev((size_t)8 * B * D * 4); m->logits = (float*)dev((size_t)B * std::max(c.vocab, m->head_vocab) * 4);
   m->tokens = (int32_t*)dev((size_t)B * c.max_ctx * 4); m->hist = (int32_t*)dev((size_t)B * 64 * 4); m->uniforms = (float*)dev((size_t)B * c.max_ctx * 4);
   m->state = (LmState*)dev(sizeof(LmState) * B);
