@@ -36,12 +36,18 @@ struct SkinnyArgs {
   //   rstd[m] = rsqrt(sum_t ss_in[t][m] / ss_dim + eps) before bias and activation -- linear, so it commutes with the contraction.
   float* xres = nullptr; const float* nw = nullptr; float* ss_out = nullptr;
   const float* ss_in = nullptr; int ss_tiles = 0; int ss_dim = 0; float eps = 0.f;
+  // LayerNorm form (the Whisper step, fragment-order kernels): ss_* hold PAIRS (sum x, sum x^2) per (tile, row); a consumer passes the
+  // Linear's folded constants c1[n] = sum_k W[n][k] gamma[k], c2[n] = sum_k W[n][k] beta[k] and its epilogue computes
+  //   LN(x) W^T = rstd (acc - mean c1) + c2      with acc = W (x * gamma), the activation the SK_RESID producer stored
+  const float* c1 = nullptr; const float* c2 = nullptr;
 };
 
 int dec_launch_embed_ln(mia_whisper* w, const LNW& ln, hipStream_t s);
 int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln, hipStream_t s);
 // Whisper step: a.A in activation fragment order, a.W in weight fragment order (LinearW::wf)
 int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s);
+// c1[n] = sum_k W[n][k] gamma[k], c2[n] = sum_k W[n][k] beta[k] for a row-major 16-bit [N][K] matrix (fp32 sums in k order)
+int dec_launch_lnfold(const void* w16, int N, int K, const float* gamma, const float* beta, float* c1, float* c2, int dtype, hipStream_t s);
 // row-major [N][K] 16-bit -> weight fragment order (dst holds ceil(N/16)*16*K elements; rows past N are zero)
 int dec_launch_repack_wfrag(const void* src, void* dst, int N, int K, hipStream_t s);
 // model-independent form (dtype = MIA_BF16 | MIA_F16); SK_SWIGLU: W rows interleaved gate/up, out[m][n/2] = silu(g)*u (16-bit)

@@ -232,7 +232,7 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const f32x4
 // skinny_prefetch at the START of the kernel, next to the operand loads: fetched in the epilogue they added an L2 round trip to every
 // biased GEMM of the chain, after the reduction barrier where nothing hides it.
 template <int NT>
-struct SkinnyPre { float bs[NT][4]; int pos[2]; };
+struct SkinnyPre { float bs[NT][4]; int pos[2]; float c1[NT][4], c2[NT][4]; };
 
 template <int MODE, int NT>
 __device__ __forceinline__ SkinnyPre<NT> skinny_prefetch(const SkinnyArgs& a, int n0, int m0, int lane) {
@@ -243,6 +243,19 @@ __device__ __forceinline__ SkinnyPre<NT> skinny_prefetch(const SkinnyArgs& a, in
     const int n = n0 + 16 * t + 4 * c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) p.bs[t][j] = (MODE != SK_PARTIAL && a.bias && n + j < a.N) ? a.bias[n + j] : 0.f;
+    // LayerNorm fold constants of a consumer (SkinnyArgs::c1 / c2): one 16-byte load each (n is a multiple of 4, the arrays hipMalloc'ed)
+    if (a.c1 && n + 3 < a.N) {
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(a.c1 + n), v2 = *reinterpret_cast<const f32x4*>(a.c2 + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { p.c1[t][j] = v1[j]; p.c2[t][j] = v2[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = a.c1 && n + j < a.N;
+        p.c1[t][j] = in ? a.c1[n + j] : 0.f;
+        p.c2[t][j] = in ? a.c2[n + j] : 0.f;
+      }
+    }
   }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -254,7 +267,7 @@ __device__ __forceinline__ SkinnyPre<NT> skinny_prefetch(const SkinnyArgs& a, in
 
 template <typename T, int MODE, int NT>
 __device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], const SkinnyPre<NT>& pre, int n0, int m0, int split,
-                                                  int lane) {
+                                                  int lane, const float* st = nullptr) {
   static_assert(MODE != SK_SWIGLU, "SK_SWIGLU is stored by skinny_store");
   const int r = lane & 15, c = lane >> 4;
 #pragma unroll
@@ -268,6 +281,11 @@ __device__ __forceinline__ void skinny_epilogue_v(const SkinnyArgs& a, const f32
       const int m = m0 + mt * 16 + r;
       if (m >= a.M) continue;
       f32x4 v = acc[t][mt];
+      if (a.c1 && st) {      // the activation was x * gamma (SK_RESID producer): LN(x) W^T = rstd (acc - mean c1) + c2
+        const float mean = st[2 * (mt * 16 + r)], rstd = st[2 * (mt * 16 + r) + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rstd * (v[j] - mean * pre.c1[t][j]) + pre.c2[t][j];
+      }
       if (MODE == SK_PARTIAL) {
         float* dst = reinterpret_cast<float*>(a.out) + ((int64_t)split * a.M + m) * a.N + n;
         if (full && (a.N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
@@ -561,6 +579,26 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
   skinny_store<T, MODE, NT>(a, acc, n0, m0, split, lane, rs);
 }
 
+// c1[n] = sum_k W[n][k] gamma[k], c2[n] = sum_k W[n][k] beta[k]: one wave per row of a row-major 16-bit matrix (load time, once per Linear)
+template <typename T>
+__global__ __launch_bounds__(256) void dec_lnfold(const uint16_t* __restrict__ w, int N, int K, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ c1, float* __restrict__ c2) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const uint16_t* wr = w + (int64_t)row * K;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane; k < K; k += 64) { const float v = T::to_f32(wr[k]); s1 = fmaf(v, gamma[k], s1); s2 = fmaf(v, beta[k], s2); }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { c1[row] = s1; c2[row] = s2; }
+}
+
+int dec_launch_lnfold(const void* w16, int N, int K, const float* gamma, const float* beta, float* c1, float* c2, int dtype, hipStream_t s) {
+  if (!w16 || !gamma || !beta || !c1 || !c2 || N <= 0 || K <= 0) return -1;
+  if (dtype == MIA_F16) hipLaunchKernelGGL(dec_lnfold<F16>, dim3((N + 3) / 4), dim3(256), 0, s, (const uint16_t*)w16, N, K, gamma, beta, c1, c2);
+  else hipLaunchKernelGGL(dec_lnfold<BF16>, dim3((N + 3) / 4), dim3(256), 0, s, (const uint16_t*)w16, N, K, gamma, beta, c1, c2);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The Whisper step's skinny GEMMs: both operands in MFMA-fragment order (decode.h), so every wave load instruction is one
 // contiguous 1 KB, and an epilogue that stores a lane's 4 consecutive columns as one 8- or 16-byte word.
@@ -595,10 +633,113 @@ int dec_launch_repack_wfrag(const void* src, void* dst, int N, int K, hipStream_
 // short K slice per wave (NSTEP K-steps, host-checked K == 32 * S * NW * NSTEP): every load ahead of the first MFMA.  Weights are
 // loaded non-temporal (measured against default-policy loads, hoping the 184 MB of layer weights would stay in the 256 MB MALL from
 // step to step: they do not, 0.424 vs 0.418 ms per step)
+// LayerNorm carried across the step's GEMM chain (decode.h): (mean, rstd) of the workgroup's rows from the producer's per-tile
+// (sum x, sum x^2) pairs.  The NW waves share the rows (wave w takes rows w, w + NW, ...), lanes take tiles t = lane, lane + 64, ...
+// (fixed-order sums); results go to LDS st[row][2] and are read by the epilogue behind the reduction barrier (NW == 1: same wave).
+template <int NW>
+struct LnStat {
+  // 64 lanes = 4 row groups x 16 tile lanes; (wave, row group) = one of NW * 4 slots, each owning RPS consecutive rows.  A lane sums
+  // its tiles t = l16, l16 + 16, ... locally in that order, the 16 tile lanes of a group are then added by one DPP row reduction:
+  // every load of the wave is in flight at once and the summation order is fixed.  issue() runs FIRST in the kernel -- its loads are the
+  // oldest of the wave, so finish() can wait for them alone (vmcnt counts in order) while the weight stream issued after them is still in
+  // flight; a row-at-a-time loop paid one memory round trip per row (3.5 us on the step's 5 us GEMMs), and loads issued behind the
+  // weights made the wave drain its whole queue before the first MFMA.
+  static constexpr int RPS = NW >= 8 ? 1 : 8 / NW;             // rows per slot: 32 rows over min(NW * 4, 32) slots
+  static constexpr int MAXU = 8;                               // tiles <= 128 (D <= 2048)
+  f32x2 v[MAXU][RPS];
+  int j0, rows;
+  bool on;
+  __device__ __forceinline__ void issue(const SkinnyArgs& a, int m0, int wave, int lane) {
+    on = a.ss_in != nullptr && a.c1 != nullptr;
+    const int rg = lane >> 4, l16 = lane & 15;
+    j0 = (wave * 4 + rg) * RPS;
+    rows = a.M - m0 < 32 ? a.M - m0 : 32;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u)
+#pragma unroll
+      for (int i = 0; i < RPS; ++i) v[u][i] = (f32x2){0.f, 0.f};
+    if (!on) return;
+    const f32x2* ss = reinterpret_cast<const f32x2*>(a.ss_in);
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+      const int t = l16 + 16 * u;
+      if (t < a.ss_tiles) {
+        if (RPS >= 2 && (a.M & 1) == 0) {                      // two rows per 16-byte load (row pairs are 16-byte aligned when M is even)
+#pragma unroll
+          for (int i = 0; i + 1 < RPS; i += 2)
+            if (j0 + i < rows) {
+              const f32x4 p = *reinterpret_cast<const f32x4*>(ss + (int64_t)t * a.M + m0 + j0 + i);
+              v[u][i] = (f32x2){p[0], p[1]}; v[u][i + 1] = (f32x2){p[2], p[3]};     // (row j + 1 >= rows: never stored)
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < RPS; ++i)
+            if (j0 + i < rows) v[u][i] = ss[(int64_t)t * a.M + m0 + j0 + i];
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void finish(const SkinnyArgs& a, float* st, int lane) {
+    if (!on) return;
+    const int l16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < RPS; ++i) {
+      float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < MAXU; ++u) { v1 += v[u][i][0]; v2 += v[u][i][1]; }
+      v1 += dpp_f32<0xB1>(v1); v1 += dpp_f32<0x4E>(v1); v1 += dpp_f32<0x141>(v1); v1 += dpp_f32<0x140>(v1);
+      v2 += dpp_f32<0xB1>(v2); v2 += dpp_f32<0x4E>(v2); v2 += dpp_f32<0x141>(v2); v2 += dpp_f32<0x140>(v2);
+      const int j = j0 + i;
+      if (l16 == 0 && j < rows) {
+        const float mean = v1 / (float)a.ss_dim;
+        const float var = fmaxf(v2 / (float)a.ss_dim - mean * mean, 0.f);
+        st[2 * j] = mean; st[2 * j + 1] = rsqrtf(var + a.eps);
+      }
+    }
+  }
+};
+
+// SK_RESID epilogue of the fragment-order kernels: x[m][n] += acc + bias in place (fp32 residual stream, row stride N); the next
+// block's activation x * gamma (its LayerNorm gain; mean / rstd / beta are applied by the consumer) in activation FRAGMENT order;
+// per-tile (sum x, sum x^2) pairs.  Lane holds C[m = m0 + 16 mt + r][n = n0 + 16 t + 4 c + j].
+template <typename T, int NT>
+__device__ __forceinline__ void skinny_resid_frag(const SkinnyArgs& a, const f32x4 (&acc)[NT][2], int n0, int m0, int lane) {
+  const int r = lane & 15, c = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + 4 * c;               // host-checked: N % 32 == 0
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(a.nw + n);
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = m0 + mt * 16 + r;
+      float s1 = 0.f, s2 = 0.f;
+      if (m < a.M) {
+        float* xp = a.xres + (int64_t)m * a.N + n;
+        f32x4 x = *reinterpret_cast<const f32x4*>(xp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] += acc[t][mt][j] + bv[j]; s1 += x[j]; s2 += x[j] * x[j]; }
+        *reinterpret_cast<f32x4*>(xp) = x;
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + afrag_index(m, n, a.N)) =
+            (u32x2){pack2<T>(x[0] * gv[0], x[1] * gv[1]), pack2<T>(x[2] * gv[2], x[3] * gv[3])};
+      }
+      // the tile's 16 columns live in lanes r, r + 16, r + 32, r + 48: fixed-order sums (c = 0, 1, 2, 3)
+      const float a1 = __shfl(s1, r + 16, 64), a2 = __shfl(s1, r + 32, 64), a3 = __shfl(s1, r + 48, 64);
+      const float b1 = __shfl(s2, r + 16, 64), b2 = __shfl(s2, r + 32, 64), b3 = __shfl(s2, r + 48, 64);
+      if (c == 0 && m < a.M)
+        *reinterpret_cast<f32x2*>(a.ss_out + ((int64_t)((n0 >> 4) + t) * a.M + m) * 2) = (f32x2){((s1 + a1) + a2) + a3, ((s2 + b1) + b2) + b3};
+    }
+  }
+}
+
 template <typename T, int MODE, int NT, int NSTEP, int NW>
 __global__ __launch_bounds__(64 * NW) void dec_skinny_fflat(SkinnyArgs a) {
+  __shared__ float st[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int split = blockIdx.y, z = blockIdx.z;
+  LnStat<NW> lnstat;
+  lnstat.issue(a, z * 32, wave, lane);
   const int ksteps = a.K >> 5, tiles = (a.N + 15) >> 4;
   const int ks0 = (split * NW + wave) * NSTEP;
   const uint16_t* wp[NT];
@@ -618,6 +759,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fflat(SkinnyArgs a) {
     fa1[u] = *reinterpret_cast<const s16x8*>(ap + 1024 * u + 512);
   }
   __builtin_amdgcn_sched_barrier(0);   // keep every load ahead of the first MFMA
+  lnstat.finish(a, st, lane);          // waits for the statistics alone; the operand loads issued after them stay in flight
   f32x4 acc[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -629,14 +771,18 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fflat(SkinnyArgs a) {
       acc[n][1] = T::mfma16(fw[u][n], fa1[u], acc[n][1]);
     }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_epilogue_v<T, MODE, NT>(a, acc, pre, blockIdx.x * (16 * NT), z * 32, split, lane);
+  if constexpr (MODE == SK_RESID) skinny_resid_frag<T, NT>(a, acc, blockIdx.x * (16 * NT), z * 32, lane);
+  else skinny_epilogue_v<T, MODE, NT>(a, acc, pre, blockIdx.x * (16 * NT), z * 32, split, lane, st);
 }
 
 // any K slice per wave (K == 32 * S * NW * steps): a ring of four register batches of KB K-steps, three in flight
 template <typename T, int MODE, int NT, int KB, int NW>
 __global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
+  __shared__ float st[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int split = blockIdx.y, z = blockIdx.z;
+  LnStat<NW> lnstat;
+  lnstat.issue(a, z * 32, wave, lane);
   const int ksteps = a.K >> 5, tiles = (a.N + 15) >> 4;
   const int per_wave = ksteps / (a.S * NW);
   const int ks0 = (split * NW + wave) * per_wave;
@@ -677,6 +823,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
     load_batch(b0, 0);
     if (nb > 1) load_batch(b1, KB);
     if (nb > 2) load_batch(b2, 2 * KB);
+    lnstat.finish(a, st, lane);          // the statistics were issued first: this waits for them alone
     for (int i = 0; i < nb; i += 4) {
       if (i + 3 < nb) load_batch(b3, (i + 3) * KB);
       mma_batch(b0);
@@ -691,7 +838,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
       mma_batch(b3);
     }
     ks = nb * KB;
-  }
+  } else lnstat.finish(a, st, lane);
   for (; ks < per_wave; ++ks) {
     const s16x8 fa0 = *reinterpret_cast<const s16x8*>(ap + 1024 * ks);
     const s16x8 fa1 = *reinterpret_cast<const s16x8*>(ap + 1024 * ks + 512);
@@ -703,7 +850,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
     }
   }
   if (!skinny_wave_reduce<NT, NW>(acc, wave, lane)) return;
-  skinny_epilogue_v<T, MODE, NT>(a, acc, pre, blockIdx.x * (16 * NT), z * 32, split, lane);
+  if constexpr (MODE == SK_RESID) skinny_resid_frag<T, NT>(a, acc, blockIdx.x * (16 * NT), z * 32, lane);
+  else skinny_epilogue_v<T, MODE, NT>(a, acc, pre, blockIdx.x * (16 * NT), z * 32, split, lane, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1614,23 +1762,32 @@ int skinny_gemm_q_launch(const SkinnyArgs& a, const uint32_t* wfrag, const float
 template <typename T, int MODE>
 static int skinny_frag_launch_m(const SkinnyArgs& a, hipStream_t s) {
   const int tiles = (a.N + 15) / 16, zb = (a.M + 31) / 32, ksteps = a.K / 32;
-  if (MODE == SK_OUTF32) {   // the vocabulary-wide logits GEMM (bandwidth-bound): 64 columns per one-wave workgroup, ring pipeline
+  if constexpr (MODE == SK_OUTF32) {   // the vocabulary-wide logits GEMM (bandwidth-bound): 64 columns per one-wave workgroup, ring pipeline
     hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 4, 2, 1>), dim3((tiles + 3) / 4, a.S, zb), dim3(64), 0, s, a);
     return 0;
-  }
-  // K of a split is divided over the most waves of {4, 2, 1} that take whole K-steps (summed through LDS in wave order)
-  const int per_split = ksteps / a.S;
-  const int NW = per_split % 4 == 0 ? 4 : per_split % 2 == 0 ? 2 : 1;
-  const int nstep = per_split / NW;
-  const dim3 grid(tiles, a.S, zb);
+  } else {
+    // K of a split is divided over the most waves of {4, 2, 1} that take whole K-steps (summed through LDS in wave order)
+    const int per_split = ksteps / a.S;
+    const dim3 grid(tiles, a.S, zb);
+    if constexpr (MODE == SK_RESID) {
+      // no cross-workgroup split (the epilogue owns its slice of the residual rows): only N / 16 workgroups, so K goes over 16 or 8 waves
+      if (per_split == 160) { hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 2, 16>), grid, dim3(1024), 0, s, a); return 0; }   // (all-loads-first would need > 128 VGPRs at 16 waves)
+      if (per_split == 80) { hipLaunchKernelGGL((dec_skinny_fflat<T, MODE, 1, 10, 8>), grid, dim3(512), 0, s, a); return 0; }
+      if (per_split == 40) { hipLaunchKernelGGL((dec_skinny_fflat<T, MODE, 1, 5, 8>), grid, dim3(512), 0, s, a); return 0; }
+      if (per_split % 16 == 0 && per_split >= 64) { hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 16>), grid, dim3(1024), 0, s, a); return 0; }
+      if (per_split % 8 == 0 && per_split >= 16) { hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 8>), grid, dim3(512), 0, s, a); return 0; }
+    }
+    const int NW = per_split % 4 == 0 ? 4 : per_split % 2 == 0 ? 2 : 1;
+    const int nstep = per_split / NW;
 #define FF(NS_)                                                                                                       \
-  if (NW == 4 && nstep == NS_) { hipLaunchKernelGGL((dec_skinny_fflat<T, MODE, 1, NS_, 4>), grid, dim3(256), 0, s, a); return 0; }
-  FF(10) FF(5) FF(8) FF(6) FF(4) FF(3) FF(2) FF(1)
+    if (NW == 4 && nstep == NS_) { hipLaunchKernelGGL((dec_skinny_fflat<T, MODE, 1, NS_, 4>), grid, dim3(256), 0, s, a); return 0; }
+    FF(10) FF(5) FF(8) FF(6) FF(4) FF(3) FF(2) FF(1)
 #undef FF
-  if (NW == 4) hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 4>), grid, dim3(256), 0, s, a);
-  else if (NW == 2) hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 2>), grid, dim3(128), 0, s, a);
-  else hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 1>), grid, dim3(64), 0, s, a);
-  return 0;
+    if (NW == 4) hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 4>), grid, dim3(256), 0, s, a);
+    else if (NW == 2) hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 2>), grid, dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((dec_skinny_fring<T, MODE, 1, 1, 1>), grid, dim3(64), 0, s, a);
+    return 0;
+  }
 }
 
 template <typename T>
@@ -1640,6 +1797,7 @@ static int skinny_frag_launch_t(const SkinnyArgs& a, int mode, hipStream_t s) {
     case SK_OUTF32: return skinny_frag_launch_m<T, SK_OUTF32>(a, s);
     case SK_PARTIAL: return skinny_frag_launch_m<T, SK_PARTIAL>(a, s);
     case SK_QKV: return skinny_frag_launch_m<T, SK_QKV>(a, s);
+    case SK_RESID: return skinny_frag_launch_m<T, SK_RESID>(a, s);
     default: return -1;
   }
 }
@@ -1648,6 +1806,8 @@ int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t
   if (!a.A || !a.W || !a.out || a.M <= 0 || a.N <= 0 || a.S <= 0 || a.K % (32 * a.S) != 0) return -1;
   if (mode == SK_QKV && (a.D % 64 != 0 || a.N != 3 * a.D || (a.ldo & 3) || !a.cache_k || !a.cache_v || !a.pos)) return -1;
   if (mode == SK_OUT16 && a.out_frag && a.N % 32 != 0) return -1;
+  if (mode == SK_RESID && (a.S != 1 || a.N % 32 != 0 || !a.xres || !a.nw || !a.ss_out)) return -1;
+  if (a.c1 && (!a.c2 || !a.ss_in || a.ss_tiles <= 0 || a.ss_dim <= 0)) return -1;
   return w->dtype == MIA_F16 ? skinny_frag_launch_t<F16>(a, mode, s) : skinny_frag_launch_t<BF16>(a, mode, s);
 }
 

@@ -22,6 +22,10 @@ struct LinearW {
   void* w = nullptr;       // 16-bit [N][K]
   void* wf = nullptr;      // decoder only: the same matrix in MFMA-fragment order (decode.h), read by the step's skinny GEMMs
   float* b = nullptr;      // fp32 [N] or null
+  // decoder Linears fed by a LayerNorm: c1[n] = sum_k W[n][k] gamma[k], c2[n] = sum_k W[n][k] beta[k] (fp32, of the 16-bit weights), so
+  // that LN(x) W^T = rstd (W (x * gamma) - mean c1) + c2 and the step can feed x * gamma (decode.h, "LayerNorm carried across the chain")
+  float* c1 = nullptr;
+  float* c2 = nullptr;
   int N = 0, K = 0;
 };
 
@@ -78,6 +82,8 @@ struct mia_whisper {
   LNW ln_post;
   void* tok_emb = nullptr;            // 16-bit [V][D]  (row gather for the embedding)
   void* tok_emb_f = nullptr;          // the same in MFMA-fragment order (the logits GEMM of the decode step)
+  float* emb_c1 = nullptr;            // fp32 [V]: the token embedding folded with decoder.ln (LinearW::c1 / c2 of the logits GEMM)
+  float* emb_c2 = nullptr;
   float* dec_pos = nullptr;           // [n_text_ctx][D]
   std::vector<DecBlockW> dec;
   LNW dec_ln;
@@ -106,6 +112,7 @@ struct mia_whisper {
   void* da = nullptr;                 // 16-bit [B][D]  attention output
   void* dg = nullptr;                 // 16-bit [B][4D]
   float* partial = nullptr;           // fp32 [S_max][B][D] split-K partials
+  float* dstat = nullptr;             // fp32 [2][D / 16][B][2]: per-tile (sum x, sum x^2) of the residual rows, written by the SK_RESID projections
   float* logits = nullptr;            // fp32 [B][V]
   int32_t* tokens = nullptr;          // int32 [B][n_ctx]  full sequence (initial + generated)
   int32_t* n_gen = nullptr;           // int32 [B]  generated count (incl. a trailing EOT while decoding)

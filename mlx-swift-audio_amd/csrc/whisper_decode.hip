@@ -63,12 +63,22 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p, const AlignHook* hook = 
   const uint16_t* dh = (const uint16_t*)w->dh;
   // A operands (dh, da, dg) and weights (LinearW::wf) are in MFMA-fragment order (decode.h); out_frag: the output is the next GEMM's A
   auto skinny = [&](const uint16_t* A, int64_t lda, const LinearW& lw, bool use_bias, void* out, int64_t ldo, int S, int act, int mode,
-                    uint16_t* ck = nullptr, uint16_t* cv = nullptr, int out_frag = 0) {
+                    uint16_t* ck = nullptr, uint16_t* cv = nullptr, int out_frag = 0, const float* stat_in = nullptr, const LNW* next_ln = nullptr,
+                    float* stat_out = nullptr, const float* c1 = nullptr, const float* c2 = nullptr) {
     SkinnyArgs a{A, lda, (const uint16_t*)lw.wf, use_bias ? lw.b : nullptr, out, ldo, ck, cv, w->clip.pos, B, lw.N, lw.K, S, act, D, H, C};
     a.out_frag = out_frag;
+    if (stat_in) { a.ss_in = stat_in; a.ss_tiles = D / 16; a.ss_dim = D; a.eps = 1e-5f; a.c1 = c1 ? c1 : lw.c1; a.c2 = c2 ? c2 : lw.c2; }
+    if (mode == SK_RESID) { a.xres = w->dx; a.nw = next_ln->g; a.ss_out = stat_out; }
     return dec_launch_skinny(w, a, mode, s);
   };
   const int S_d = pick_split(D, 2), S_4d = pick_split(4 * D, 4);   // x 4 waves of intra-workgroup split-K each
+  // LayerNorm carried across the chain (decode.h): the three residual-writing projections of a layer (self-attention out, cross-attention
+  // out, fc2) add into x, store x * gamma of the NEXT LayerNorm as the next GEMM's operand plus per-tile (sum x, sum x^2); the GEMM that
+  // consumes it applies mean / rstd / beta through its folded constants.  Used for the two attention output projections (8 of the 12
+  // reduce + LayerNorm launches of a step go); fc2 keeps the split form (below).
+  const bool fused_ln = D % 32 == 0 && w->dec[0].qkv.c1 != nullptr;
+  float* st_a = w->dstat;                                          // two alternating buffers: a producer never overwrites what its
+  float* st_b = w->dstat + (size_t)(D / 16) * w->cap_B * 2;        // own consumer is still reading (the chain is strictly serial anyway)
   // (the split greedy head embeds the next position itself: only the very first step needs this launch, done by the caller)
   if (hook || !dec_head_is_split(p)) dec_launch_embed_ln(w, w->dec[0].attn_ln, s);
   for (int l = 0; l < p.L; ++l) {
@@ -77,6 +87,25 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p, const AlignHook* hook = 
     uint16_t* sv = (uint16_t*)w->self_v + (size_t)l * w->cap_B * C * D;
     const uint16_t* xk = (const uint16_t*)w->cross_k + (size_t)l * w->cap_B * T * D;
     const uint16_t* xv = (const uint16_t*)w->cross_v + (size_t)l * w->cap_B * T * D;
+    const LNW& next_ln = l + 1 < p.L ? w->dec[l + 1].attn_ln : w->dec_ln;
+    if (fused_ln) {
+      // self attention (its input is always a normalised row: the embedding kernel's, or the previous layer's reduce + LayerNorm)
+      if (skinny(dh, D, b.qkv, true, w->dq, D, 1, MIA_ACT_NONE, SK_QKV, sk, sv)) return -1;
+      if (dec_launch_attention(w, w->dq, sk, sv, w->da, 0, C, s)) return -1;
+      if (skinny((const uint16_t*)w->da, D, b.out, true, w->dh, D, 1, MIA_ACT_NONE, SK_RESID, nullptr, nullptr, 0, nullptr, &b.cross_ln, st_a)) return -1;
+      // cross attention (K/V primed by the encode call)
+      if (skinny(dh, D, b.cq, true, w->dq, D, 1, MIA_ACT_NONE, SK_OUT16, nullptr, nullptr, 0, st_a)) return -1;
+      if (dec_launch_attention(w, w->dq, xk, xv, w->da, T, T, s, hook ? hook->qk : nullptr, hook ? hook->head_slot + (size_t)l * H : nullptr,
+                               hook ? hook->n_slots : 0, C)) return -1;
+      if (skinny((const uint16_t*)w->da, D, b.cout, true, w->dh, D, 1, MIA_ACT_NONE, SK_RESID, nullptr, nullptr, 0, nullptr, &b.mlp_ln, st_b)) return -1;
+      // MLP.  fc2 keeps its cross-workgroup split + the reduce / LayerNorm kernel: its 13 MB over the 80 workgroups an unsplit projection
+      // has run at 1.1 TB/s (12 us measured against 7.5 + 4.9 split), and its consumers (the next q|k|v, the logits GEMM) then read a
+      // normalised row and pay nothing.
+      if (skinny(dh, D, b.mlp1, true, w->dg, 4 * D, 1, MIA_ACT_GELU, SK_OUT16, nullptr, nullptr, 1, st_b)) return -1;
+      if (skinny((const uint16_t*)w->dg, 4 * D, b.mlp2, false, w->partial, 0, S_4d, MIA_ACT_NONE, SK_PARTIAL)) return -1;
+      dec_launch_reduce_ln(w, S_4d, b.mlp2.b, next_ln, s);
+      continue;
+    }
     // self attention
     if (skinny(dh, D, b.qkv, true, w->dq, D, 1, MIA_ACT_NONE, SK_QKV, sk, sv)) return -1;
     if (dec_launch_attention(w, w->dq, sk, sv, w->da, 0, C, s)) return -1;
@@ -91,10 +120,10 @@ int enqueue_step(mia_whisper* w, const DecodeParams& p, const AlignHook* hook = 
     // MLP
     if (skinny(dh, D, b.mlp1, true, w->dg, 4 * D, 1, MIA_ACT_GELU, SK_OUT16, nullptr, nullptr, 1)) return -1;
     if (skinny((const uint16_t*)w->dg, 4 * D, b.mlp2, false, w->partial, 0, S_4d, MIA_ACT_NONE, SK_PARTIAL)) return -1;
-    dec_launch_reduce_ln(w, S_4d, b.mlp2.b, l + 1 < p.L ? w->dec[l + 1].attn_ln : w->dec_ln, s);
+    dec_launch_reduce_ln(w, S_4d, b.mlp2.b, next_ln, s);
   }
   {  // logits = ln(x) . E^T (tied embedding, TextDecoder.swift:93)
-    LinearW e; e.w = w->tok_emb; e.wf = w->tok_emb_f; e.N = p.V; e.K = D;
+    LinearW e; e.w = w->tok_emb; e.wf = w->tok_emb_f; e.N = p.V; e.K = D; e.c1 = w->emb_c1; e.c2 = w->emb_c2;
     if (skinny(dh, D, e, false, w->logits, p.V, 1, MIA_ACT_NONE, SK_OUTF32)) return -1;
   }
   if (p.trace && !hook && dec_launch_trace(w, s)) return -1;

@@ -76,6 +76,7 @@ int whisper_reserve(mia_whisper* w, int B) {
   A(da, B32 * D * 2, true);
   A(dg, B32 * 4 * D * 2, true);
   A(partial, (size_t)16 * B * D * 4, false);
+  A(dstat, (size_t)2 * ((D + 15) / 16) * B * 2 * 4, true);
   A(logits, (size_t)B * V * 4, false);
   A(tokens, (size_t)B * C * 4, true);
   A(n_gen, (size_t)B * 4, true);
@@ -109,7 +110,7 @@ int whisper_reserve(mia_whisper* w, int B) {
   // commit: raw pointers from the scratch copy, then retire the superseded set (the stream is idle)
   w->mel_pad = n.mel_pad; w->conv1_out = n.conv1_out; w->x = n.x; w->h = n.h; w->qk = n.qk; w->vt = n.vt; w->att = n.att; w->g = n.g;
   w->feat = n.feat; w->cross_k = n.cross_k; w->cross_v = n.cross_v; w->self_k = n.self_k; w->self_v = n.self_v; w->dx = n.dx; w->dh = n.dh;
-  w->dq = n.dq; w->da = n.da; w->dg = n.dg; w->partial = n.partial; w->logits = n.logits; w->tokens = n.tokens; w->n_gen = n.n_gen;
+  w->dq = n.dq; w->da = n.da; w->dg = n.dg; w->partial = n.partial; w->dstat = n.dstat; w->logits = n.logits; w->tokens = n.tokens; w->n_gen = n.n_gen;
   w->finished = n.finished; w->last_ts = n.last_ts; w->out_n = n.out_n; w->sum_logprob = n.sum_logprob; w->n_logprob = n.n_logprob;
   w->no_speech = n.no_speech; w->uniforms = n.uniforms; w->out_tokens = n.out_tokens; w->out_avg = n.out_avg; w->clip = n.clip;
   for (void* q : w->batch_allocs) (void)hipFree(q);

@@ -239,6 +239,24 @@ extern "C" mia_whisper* mia_whisper_load(mia_ctx* ctx, const mia_whisper_dims* d
       for (LinearW* lw : {&b.qkv, &b.out, &b.cq, &b.cout, &b.mlp1, &b.mlp2}) lw->wf = frag(lw->w, lw->N, lw->K);
     w->tok_emb_f = frag(w->tok_emb, d.n_vocab, D);
     if (!ok) { mia_whisper_free(w); return fail("fragment-order repack of the decoder weights failed"); }
+    // LayerNorm fold constants of every decoder Linear that consumes a LayerNorm (whisper.h LinearW::c1 / c2; decode.h)
+    auto fold = [&](const void* w16, int N, const LNW& ln, float** c1, float** c2) {
+      if (!ok || !w16) return;
+      void* p1 = nullptr; void* p2 = nullptr;
+      if (hipMalloc(&p1, (size_t)N * 4) != hipSuccess) { ok = false; return; }
+      w->allocs.push_back(p1);
+      if (hipMalloc(&p2, (size_t)N * 4) != hipSuccess) { ok = false; return; }
+      w->allocs.push_back(p2);
+      *c1 = (float*)p1; *c2 = (float*)p2;
+      if (dec_launch_lnfold(w16, N, D, ln.g, ln.b, *c1, *c2, w->dtype, ctx->stream) != 0) ok = false;
+    };
+    for (DecBlockW& b : w->dec) {
+      fold(b.qkv.w, b.qkv.N, b.attn_ln, &b.qkv.c1, &b.qkv.c2);
+      fold(b.cq.w, b.cq.N, b.cross_ln, &b.cq.c1, &b.cq.c2);
+      fold(b.mlp1.w, b.mlp1.N, b.mlp_ln, &b.mlp1.c1, &b.mlp1.c2);
+    }
+    fold(w->tok_emb, d.n_vocab, w->dec_ln, &w->emb_c1, &w->emb_c2);
+    if (!ok) { mia_whisper_free(w); return fail("LayerNorm fold of the decoder weights failed"); }
   }
   if (hipDeviceSynchronize() != hipSuccess) { mia_whisper_free(w); return fail("device error during upload"); }
   return w;
@@ -269,7 +287,7 @@ extern "C" mia_whisper* mia_whisper_clone(mia_whisper* src, mia_ctx* ctx) {
   mia_whisper* w = new mia_whisper();
   w->ctx = ctx; w->dims = root->dims; w->dtype = root->dtype; w->kpad_conv1 = root->kpad_conv1;
   w->conv1 = root->conv1; w->conv2 = root->conv2; w->enc_pos = root->enc_pos; w->enc = root->enc; w->ln_post = root->ln_post;
-  w->tok_emb = root->tok_emb; w->tok_emb_f = root->tok_emb_f; w->dec_pos = root->dec_pos; w->dec = root->dec; w->dec_ln = root->dec_ln;
+  w->tok_emb = root->tok_emb; w->tok_emb_f = root->tok_emb_f; w->emb_c1 = root->emb_c1; w->emb_c2 = root->emb_c2; w->dec_pos = root->dec_pos; w->dec = root->dec; w->dec_ln = root->dec_ln;
   w->parent = root;
   root->n_clones += 1;
   return w;
