@@ -525,6 +525,11 @@ extern "C" int mia_dac_load_encoder(mia_codec* c, const mia_dac_encoder_config* 
   mia_ctx* ctx = c->ctx;
   MIA_CHECK_ARG(ctx, c->kind == 1, "dac_load_encoder: handle is not a DAC model");
   MIA_CHECK_ARG(ctx, cfg && tensors && n_tensors > 0 && cfg->n_rates > 0 && cfg->n_rates <= 8, "dac_load_encoder: bad arguments");
+  // the RVQ kernel keeps a projected vector in <= 15 registers (codec_vq_assign_launch) and the staging buffer is sized from cb_dim;
+  // a stride-1 "rate" would not halve-pad like the reference's k = 2 s, pad = ceil(s / 2) convolution (DACModel.swift:15-38)
+  MIA_CHECK_ARG(ctx, c->cb_dim >= 1 && c->cb_dim <= 15, "dac_load_encoder: codebook_dim %d not supported by the RVQ kernel (1..15)", c->cb_dim);
+  for (int i = 0; i < cfg->n_rates; ++i)
+    MIA_CHECK_ARG(ctx, cfg->encoder_rates[i] >= 2, "dac_load_encoder: encoder rate %d must be >= 2 (got %d)", i, cfg->encoder_rates[i]);
   MIA_CHECK_ARG(ctx, cfg->encoder_dim % 32 == 0 && (cfg->encoder_dim << cfg->n_rates) == c->latent,
                 "dac_load_encoder: encoder_dim * 2^n_rates (%d) must equal the latent width (%d) and be a multiple of 32", cfg->encoder_dim << cfg->n_rates, c->latent);
   MIA_CHECK_ARG(ctx, !c->has_encoder, "dac_load_encoder: encoder already loaded");
@@ -611,7 +616,7 @@ extern "C" int mia_dac_encode(mia_codec* c, const float* pcm, int64_t n_samples,
   int rc = ensure(c, max_floats);
   if (rc != MIA_OK) return rc;
   if ((rc = ensure_buf(c, c->d_audio, c->audio_cap, (size_t)T0)) != MIA_OK) return rc;
-  if ((rc = ensure_buf(c, c->d_ze, c->ze_cap, (size_t)Tc * 16)) != MIA_OK) return rc;
+  if ((rc = ensure_buf(c, c->d_ze, c->ze_cap, (size_t)Tc * (size_t)std::max(c->cb_dim, 1))) != MIA_OK) return rc;
   if ((rc = ensure_buf(c, c->d_codes, c->codes_cap, (size_t)nq * Tc)) != MIA_OK) return rc;
   MIA_HIP(ctx, hipMemsetAsync(c->d_audio, 0, (size_t)T0 * 4, s));
   MIA_HIP(ctx, hipMemcpyAsync(c->d_audio, pcm, (size_t)n_samples * 4, mem == MIA_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
