@@ -573,6 +573,9 @@ def main():
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "phased"],
                     help="how R > 1 replicas share the GPU: pipelined = each replica runs whole passes on its own stream; phased = rounds of R passes, all encoders first, then all decoders concurrently")
     ap.add_argument("--no-config0", action="store_true", help="skip the BASELINE configs[0] leg (tiny.en, one 10 s clip: GPU + CPU at all cores and 1 thread)")
+    ap.add_argument("--streams", default="prio", choices=["single", "prio"],
+                    help="R > 1 replicas: single = each replica's whole pass on one stream; prio = decode chains on HIGH-priority streams, every replica's "
+                         "encoder half on its own normal-priority stream (mia_whisper_set_encode_stream)")
     ap.add_argument("--dp", default="abi", choices=["abi", "torch"], help="token all-gather at N > 1: mia_dp_* (RCCL behind the C ABI, ONE communicator on the rank's exchange stream) or torch.distributed")
     args = ap.parse_args()
 
@@ -632,10 +635,15 @@ def main():
         throughput.  Every pass is still a full log-mel + encode + 448-token-budget decode of 32 clips."""
 
         def __init__(self, root=None):
-            self.stream = torch.cuda.Stream()
+            prio = args.streams == "prio" and max(1, min(args.replicas, args.steps)) > 1
+            self.stream = torch.cuda.Stream(priority=-1) if prio else torch.cuda.Stream()
             self.ctx = m.Context(local_rank, stream=self.stream.cuda_stream)
             # the first replica uploads the weights; the others are clones: own activations / KV caches / step graph, shared weights
             self.model = HW.WhisperModel.load(self.ctx, dims, weights, dtype) if root is None else root.model.clone(self.ctx)
+            self.enc_stream = None
+            if prio:       # the decode chain outranks the queued tiles of another batch's encoder (include/mia.h, mia_whisper_set_encode_stream)
+                self.enc_stream = torch.cuda.Stream(priority=0)
+                self.model.set_encode_stream(self.enc_stream.cuda_stream)
             self.opts = HW.DecodingOptions(suppress_ids=S.synthetic_suppress_list(self.model.special), blank_ids=[220], max_new_tokens=args.max_new_tokens)
             with torch.cuda.stream(self.stream):
                 self.tokens = torch.zeros((B, self.opts.max_tokens), dtype=torch.int32, device="cuda")
@@ -849,7 +857,7 @@ def main():
         try:
             if args.model != "large-v3-turbo" or B != 32:
                 raise KeyError("no PMC passes for this workload")
-            pmc_name = next(n for n in ("r02_pmc_summary.json", "r01_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            pmc_name = next(n for n in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             rl["traffic"] = round(pmc["decode_step"]["hbm_bytes_per_step"] if rl["bound"] == "hbm" else pmc["encoder_gemm"]["hbm_bytes_per_launch"], 0)
             rl["traffic_source"] = f"profiles/{pmc_name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"

@@ -270,6 +270,13 @@ int mia_whisper_detect_language(mia_whisper* w, int32_t sot, int32_t n_languages
  * (latency-bound) decoders in separate phases: decoders of different batches overlap each other well, an encoder next to a decoder does
  * not. */
 int mia_whisper_encode_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right, int mem);
+/* Serving-side scheduling aid: from now on the encoder half of mia_whisper_encode_windows / mia_whisper_transcribe_windows (log-mel,
+ * encoder, cross K/V) is enqueued on `hip_stream` instead of the context's stream, ordered against it by events in both directions (the
+ * order of a handle's own work does not change).  A host that drives several handles can then create the contexts (decode chains:
+ * thousands of short dependent kernels) on HIGH-priority streams and hand every handle a normal-priority encode stream: the decode
+ * kernels of one batch are then dispatched ahead of the queued tiles of another batch's encoder instead of taking turns with them.
+ * NULL restores the single-stream form.  The stream must belong to the context's device and outlive the handle's use of it. */
+int mia_whisper_set_encode_stream(mia_whisper* w, void* hip_stream);
 int mia_whisper_transcribe_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right,
                                    const mia_decode_opts* opts, int32_t* tokens, int32_t* n_tokens, float* avg_logprob,
                                    float* no_speech_prob, int mem);

@@ -132,6 +132,12 @@ struct mia_whisper {
   DecodeParams graph_params{};
   bool graph_valid = false;
 
+  // ---- optional second stream for the encoder half (mia_whisper_set_encode_stream): the log-mel + encoder of a pass is enqueued there,
+  // ordered against the decode stream by events, so that a host can give the (latency-bound) decode chain a higher stream priority
+  // than the (throughput-bound) encoder of another batch running beside it
+  hipStream_t enc_stream = nullptr;
+  hipEvent_t ev_enc_begin = nullptr, ev_enc_end = nullptr;
+
   // ---- test hooks (never set by the product path)
   int debug_flags = 0;                // mia_whisper_set_debug: bit 0 = launch every step directly (no hipGraph), bit 1 = one-workgroup head
   float* trace = nullptr;             // mia_whisper_trace_logits: fp32 [trace_n][n_text_ctx][V], row p = the logits computed at position p

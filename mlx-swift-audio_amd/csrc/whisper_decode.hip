@@ -548,12 +548,51 @@ extern "C" int mia_whisper_detect_language(mia_whisper* w, int32_t sot, int32_t 
   return MIA_OK;
 }
 
+// The encoder half on its own stream (mia_whisper_set_encode_stream): everything between begin and end is enqueued on w->enc_stream, which
+// first waits for what the context's stream holds (the previous decode still reads the cross K/V this encode rewrites); the context's
+// stream then waits for the encoder's tail.  Within one handle the order of work is unchanged; across handles the encoder and decode
+// queues can now carry different priorities.
+struct EncStreamScope {
+  mia_whisper* w; hipStream_t saved; bool on;
+  explicit EncStreamScope(mia_whisper* w_) : w(w_), saved(w_->ctx->stream), on(w_->enc_stream != nullptr) {
+    if (!on) return;
+    (void)hipEventRecord(w->ev_enc_begin, saved);
+    (void)hipStreamWaitEvent(w->enc_stream, w->ev_enc_begin, 0);
+    w->ctx->stream = w->enc_stream;
+  }
+  ~EncStreamScope() {
+    if (!on) return;
+    (void)hipEventRecord(w->ev_enc_end, w->enc_stream);
+    w->ctx->stream = saved;
+    (void)hipStreamWaitEvent(saved, w->ev_enc_end, 0);
+  }
+};
+
+extern "C" int mia_whisper_set_encode_stream(mia_whisper* w, void* hip_stream) {
+  if (!w) return MIA_ERR_MODEL_NOT_LOADED;
+  mia_ctx* ctx = w->ctx;
+  MIA_HIP(ctx, hipSetDevice(ctx->device));
+  MIA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (w->enc_stream) MIA_HIP(ctx, hipStreamSynchronize(w->enc_stream));
+  w->enc_stream = (hipStream_t)hip_stream;
+  if (w->enc_stream && !w->ev_enc_begin) {
+    MIA_HIP(ctx, hipEventCreateWithFlags(&w->ev_enc_begin, hipEventDisableTiming));
+    MIA_HIP(ctx, hipEventCreateWithFlags(&w->ev_enc_end, hipEventDisableTiming));
+  }
+  return MIA_OK;
+}
+
 extern "C" int mia_whisper_encode_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right, int mem) {
   if (!w) return MIA_ERR_MODEL_NOT_LOADED;
   mia_ctx* ctx = w->ctx;
   MIA_CHECK_ARG(ctx, pcm && offs && B > 0, "encode_windows: null input or B <= 0");
   MIA_CHECK_ARG(ctx, mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE, "encode_windows: bad mem");
   MIA_HIP(ctx, hipSetDevice(ctx->device));
+  {  // a larger batch re-allocates the batch buffers: that synchronises the CONTEXT's stream, so it happens before the scope
+    const int rc0 = whisper_reserve(w, B);
+    if (rc0 != MIA_OK) return rc0;
+  }
+  EncStreamScope scope(w);
   int rc = whisper_reserve(w, B);
   if (rc != MIA_OK) return rc;
   const mia_whisper_dims& d = w->dims;

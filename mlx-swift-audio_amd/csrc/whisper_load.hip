@@ -271,6 +271,8 @@ extern "C" void mia_whisper_free(mia_whisper* w) {
   if (w->step_graph_n) (void)hipGraphExecDestroy(w->step_graph_n);
   for (void* p : w->batch_allocs) (void)hipFree(p);
   for (void* p : w->allocs) (void)hipFree(p);
+  if (w->ev_enc_begin) (void)hipEventDestroy(w->ev_enc_begin);
+  if (w->ev_enc_end) (void)hipEventDestroy(w->ev_enc_end);
   if (w->trace) (void)hipFree(w->trace);
   if (w->trace_clips) (void)hipFree(w->trace_clips);
   if (w->parent) w->parent->n_clones -= 1;

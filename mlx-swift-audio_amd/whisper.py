@@ -174,6 +174,14 @@ class WhisperModel:
         lib.mia_whisper_set_debug.argtypes = [C.c_void_p, C.c_int]
         self.ctx.check(lib.mia_whisper_set_debug(self.h, int(flags)))
 
+    def set_encode_stream(self, hip_stream: int | None) -> None:
+        """mia_whisper_set_encode_stream: run the encoder half of every window on another HIP stream (raw pointer, e.g.
+        torch.cuda.Stream(...).cuda_stream); None restores the single-stream form."""
+        lib = self.ctx.lib
+        lib.mia_whisper_set_encode_stream.restype = C.c_int
+        lib.mia_whisper_set_encode_stream.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx.check(lib.mia_whisper_set_encode_stream(self.h, hip_stream))
+
     def trace_logits(self, clips: list[int]) -> None:
         """Test hook (mia_whisper_trace_logits): keep the raw step logits of these batch rows; [] switches the trace off."""
         lib = self.ctx.lib
