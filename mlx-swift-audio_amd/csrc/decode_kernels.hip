@@ -173,10 +173,14 @@ __device__ __forceinline__ bool skinny_wave_reduce(f32x4 (&acc)[NT][2], int wave
 // reduction barrier when the workgroup has one) reads rs[row].  Lanes take tiles t = lane, lane + 64, ...; fixed-order sums.
 __device__ __forceinline__ void skinny_rstd_prepare(const SkinnyArgs& a, float* rs, int m0, int wave, int lane) {
   if (!a.ss_in || wave != 0) return;
+  // (the LM step uses this form with at most 4 rows -- lm.hip keeps the unfused chain for wider batches -- so a row at a time is fine:
+  // all of a row's loads are issued together, one wave reduction per row)
   const int rows = a.M - m0 < 32 ? a.M - m0 : 32;
   for (int j = 0; j < rows; ++j) {
-    float v = 0.f;
-    for (int t = lane; t < a.ss_tiles; t += 64) v += a.ss_in[(int64_t)t * a.M + m0 + j];
+    float p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int t = lane + 64 * u; p[u] = t < a.ss_tiles ? a.ss_in[(int64_t)t * a.M + m0 + j] : 0.f; }   // tiles <= 512
+    float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     v = wave_sum(v);
     if (lane == 0) rs[j] = rsqrtf(v / (float)a.ss_dim + a.eps);
   }
@@ -1714,7 +1718,9 @@ static void skinny_qi_launch_m(const SkinnyArgs& a, const QFrag& q, int mode, hi
   // 4 tiles per wave only when one tile per wave would put more than ~16 waves on every SIMD anyway (the vocabulary-wide head): the
   // activation fragments and group sums are then reused four times.  Otherwise one tile per wave and as many waves per workgroup
   // (1..4, splitting the K range) as keep 2+ blocks per wave -- the kernel hides its memory latency by occupancy.
-  const bool nt4 = (int64_t)tiles * a.S * zb >= 16384;
+  // ... and whenever more than 16 rows are multiplied: every wave then loads 32 activation rows per K-step (8 KB per 128-input block against
+  // 1 KB of codes), which four tiles share (32 sequences side by side, Orpheus-3B: 4 900 tokens/s with one tile per wave, 11 000 with four)
+  const bool nt4 = (int64_t)tiles * a.S * zb >= 16384 || (a.M > 16 && (int64_t)((tiles + 3) / 4) * a.S * zb >= 192);
   int nw = 1;
   for (int cand : {4, 3, 2}) if (per_split % cand == 0 && (per_split / cand >= 2 || cand == 2)) { nw = cand; break; }
 #define QI_GO(MODE_, NT_, NW_) hipLaunchKernelGGL((skinny_gemm_qi<T, MODE_, NT_, NW_, M16, NP>), dim3((tiles + NT_ - 1) / NT_, a.S, zb), dim3(64 * NW_), 0, s, a, q)
