@@ -394,7 +394,10 @@ int mia_lm_generate(mia_lm* lm, const int32_t* prompt, int n_prompt, const mia_l
  * mia_lm_set_batch sizes the per-sequence state (K/V caches, repetition windows, ...) for up to max_batch <= 32 sequences;
  * mia_lm_generate_batch runs mia_lm_generate's loop for n_seq prompts side by side -- one read of the weights per step for all of
  * them.  prompts: all ids back to back, prompt_offsets [n_seq + 1]; uniforms [n_seq][max_new_tokens]; out_tokens
- * [n_seq][max_new_tokens]; n_out [n_seq].  Sequence b's output equals mia_lm_generate(prompt b, uniforms row b).  Host pointers. */
+ * [n_seq][max_new_tokens]; n_out [n_seq].  Sequence b's output equals mia_lm_generate(prompt b, uniforms row b) on the same handle
+ * capacity: a sequence's ids never depend on the batch it sits in.  (The capacity selects the step's kernel chain -- up to 4 sequences
+ * the low-latency chain with the RMSNorm carried across the GEMMs, above that the split-K chain -- so runs under capacities on
+ * different sides of 4 agree to fp32 summation order, not bit for bit.)  Host pointers. */
 int mia_lm_set_batch(mia_lm* lm, int max_batch);
 int mia_lm_generate_batch(mia_lm* lm, const int32_t* prompts, const int32_t* prompt_offsets, int n_seq, const mia_lm_sampler* sampler,
                           const float* uniforms, int32_t* out_tokens, int32_t* n_out);

@@ -979,7 +979,9 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
   // launches less per layer than "GEMM -> split-K partials -> reduce + norm kernel" (5.1 us each on Orpheus-3B, 56 per token).
   // Up to 4 sequences (the latency-critical case).  Wider batches keep the split-K + reduce / norm chain: without a cross-workgroup split the
   // residual-writing projections run on hidden / 16 workgroups only (32 sentences side by side, Orpheus-3B: 6 400 tokens/s fused, 9 500 split).
-  const bool fused_norm = (D % 16) == 0 && D <= 8192 && nb <= 4;
+  // The choice follows the handle's CAPACITY (mia_lm_set_batch), not the rows of this call: within one capacity every call -- one sequence
+  // or many -- runs the same chain, so a sequence's ids do not depend on which batch it sits in.
+  const bool fused_norm = (D % 16) == 0 && D <= 8192 && m->B_cap <= 4;
   const int ss_tiles = D / 16;
   float* ss_o = m->ss;                                   // written by o-proj, read by gate|up
   float* ss_d = m->ss + (size_t)ss_tiles * m->B_cap;     // written by down-proj, read by the next q|k|v (or the head)

@@ -132,7 +132,10 @@ def test_generate_matches_oracle(ctx, cfg_name):
 @pytest.mark.parametrize("cfg_name", ["llama-micro128", "qwen-micro"])
 def test_generate_batch_equals_single_sequence_runs(ctx, cfg_name):
     """Sentence-level batching: n prompts of different lengths decoded side by side (rows of the same skinny GEMMs, own K/V cache,
-    repetition window, uniforms and stop state each) give, sequence by sequence, exactly the ids of n separate generate() calls."""
+    repetition window, uniforms and stop state each) give, sequence by sequence, exactly the ids of n separate generate() calls on the
+    same handle capacity (the capacity picks the step's kernel chain -- <= 4: RMSNorm carried across the GEMMs, > 4: split-K + reduce --
+    so within one capacity a sequence's ids never depend on its batch; across the two chains they agree to fp32 summation order, which
+    the last check states through the oracle's boundary rule)."""
     import mlx_swift_audio_amd as m
     from mlx_swift_audio_amd import lm as HL
     cfg = S.LM_CONFIGS[cfg_name]
@@ -144,16 +147,24 @@ def test_generate_batch_equals_single_sequence_runs(ctx, cfg_name):
     u = rng.random((len(prompts), n_new)).astype(np.float32)
     stop = int(rng.integers(0, cfg.vocab))                 # some sequences stop early, the others run to max_new_tokens
     kw = dict(temperature=0.8, top_p=0.9, rep_penalty=1.2, rep_window=16, max_new_tokens=n_new, stop_ids=(stop,))
-    solo = [model.generate(p, u[b], **kw) for b, p in enumerate(prompts)]
     model.set_batch(8)
+    solo = [model.generate(p, u[b], **kw) for b, p in enumerate(prompts)]   # one sequence at a time on the capacity-8 handle
     both = model.generate_batch(prompts, u, **kw)
     assert both == solo
     assert model.generate_batch(prompts[:2], u[:2], **kw) == solo[:2]      # a smaller batch on the same state
-    assert model.generate(prompts[1], u[1], **kw) == solo[1]               # the single-sequence entry point still works on row 0
     with pytest.raises(m.MiaError):
         model.generate_batch(prompts * 2, np.concatenate([u, u]), **kw)   # 12 sequences > set_batch(8)
+    # the low-latency chain (capacity <= 4): again batch == solo, bit for bit
+    model.set_batch(4)
+    solo4 = [model.generate(p, u[b], **kw) for b, p in enumerate(prompts[:4])]
+    assert model.generate_batch(prompts[:4], u[:4], **kw) == solo4
     model.set_batch(1)
-    assert model.generate(prompts[2], u[2], **kw) == solo[2]
+    assert model.generate(prompts[2], u[2], **kw) == solo4[2]
+    # the two chains against the fp32 oracle under the sampling boundary rule (they differ from each other by fp32 summation order only)
+    ora = OL.LMOracle(cfg, w)
+    for b in (1, 3):
+        for got in (solo[b], solo4[b]):
+            _sampled_ids_follow_oracle(got, ora, prompts[b], kw, u[b], 2e-2)
     model.close()
 
 
@@ -391,7 +402,7 @@ def test_packed_step_mid_size_batch_32(ctx, bits):
     kw = dict(temperature=0.8, top_p=0.9, rep_penalty=1.1, rep_window=8, max_new_tokens=16, stop_ids=(cfg.vocab - 1,))
     q = model.generate_batch(prompts, ub, **kw)
     assert all(0 <= t < cfg.vocab for seq in q for t in seq)
-    model.set_batch(1)
     for b in (0, 7, 31):            # rows of a 32-row batch (M > 16: both MFMA halves) equal the single-sequence (M16) kernel's ids
+                                    # on the same capacity (same kernel chain; mia.h, mia_lm_generate_batch)
         assert model.generate(prompts[b], ub[b], **kw) == q[b], b
     model.close()
