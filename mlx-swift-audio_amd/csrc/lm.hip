@@ -68,7 +68,7 @@ struct mia_lm {
   int32_t* tokens = nullptr;    // [max_ctx] full sequence
   int32_t* hist = nullptr;      // [64] repetition window (ring, oldest first)
   float* uniforms = nullptr;    // [max_ctx]
-  uint32_t* hist_bins = nullptr;  // sampler scratch
+  void* smx = nullptr;            // SmxWs[B]: sampler scratch, one per sequence (slice records + radix slabs)
   LmState* state = nullptr;
   hipGraphExec_t graph = nullptr;       // one decode step (forward / top-p sampler / RAS sampler), re-captured when its sampler arguments change
   int graph_mode = -1;                  // 0 forward, 1 top-p, 2 RAS
@@ -400,29 +400,88 @@ __device__ __forceinline__ float blk1024_max(float v, float* sh) {
   return r;
 }
 
-// Level histograms of the radix select live in LDS.  Measured on gfx950 (tools/micro/lds_atomic_rate.hip, 1024 threads): ds_add_f32 to
-// lane-distinct words runs at 0.8 lane-ops/ns, ds_add_u32 at 37, ds_add_u64 at 25 -- float LDS atomics are ~40x slower than integer
-// ones, and 157 k of them cost 200 us.  So a bin holds ONE u64: (count << 44) | sum of the bits below the level's digit.  Every p of
-// a bin shares sign and exponent (the top level's digit IS sign|exponent), so p = base + low * ulp and the bin's sum is exactly
-// count * base + ulp * sum(low): integer atomics, order-independent, exact.  Copies per lane group keep a wave whose lanes all hit
-// one bin (the usual case at the top level) from serialising: 64 copies x 128 bins at the top (p <= 1 -> exponent field <= 127).
-constexpr int SMP_W[3] = {9, 12, 11};                 // digit widths, top down: sign|exponent, 12 mantissa bits, 11 mantissa bits
-constexpr int SMP_SH[3] = {23, 11, 0};
-constexpr int SMP_NB[3] = {128, 4096, 2048};
-constexpr int SMP_CP[3] = {64, 4, 8};                 // copies
-constexpr int SMP_ST[3] = {129, 4096 + 4, 2048 + 4};  // copy stride in u64 words (skews equal bins across banks)
-constexpr size_t SMP_LDS_BYTES = (size_t)4 * (4096 + 4) * 8;              // 131 200 B, the largest level
-constexpr int SMP_CNT_SHIFT = 44;                     // V < 2^20 tokens, 23-bit `low`: 43 bits of sum
-
 template <typename V>
 __device__ __forceinline__ V wave_incl_scan(V v, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const V t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
   return v;
 }
-// exclusive prefix over the 1024 threads of the workgroup (thread order); sh: 16 floats/ints of scratch
-template <typename V>
-__device__ __forceinline__ V blk1024_excl_scan(V v, V* sh) {
+
+// ---- the top-p sampler, split over the vocabulary: SMX_G workgroups per sequence, one kernel per dependent phase ----
+// One workgroup walking V = 156 940 logits six times took 82-91 us per token (46 GB/s: what one CU streams), 4-7 % of an Orpheus-3B
+// step.  Here each of 32 workgroups owns one contiguous slice of the vocabulary (4 905 tokens at that V), holds it in registers
+// (24 loads in flight per thread: one memory round trip per kernel) and the phases that need a vocabulary-wide result are separate
+// kernels of the step graph (a kernel boundary inside a hipGraph costs 1.5 us, a grid barrier 4-5):
+//   smx_max   repetition penalty on the slice's tokens; slice maximum of z / T
+//   smx_exp   p = exp(z / T - max) written in place; slice sum; radix level 0 (sign | exponent) histogram of the slice
+//   smx_level<1..3>  walk the previous level's merged histogram down to the bin where the descending cumulative sum crosses
+//             top_p * total, then histogram the next 8 / 8 / 7 mantissa bits of the slice's members of that bin (level 3 also sums the
+//             slice's probabilities ABOVE the bin: they are kept whatever the last 7 bits turn out to be)
+//   smx_draw  one workgroup: walks the last level -> the exact bit pattern of the smallest kept probability + how many of its ties are
+//             kept; every slice's kept sum and tie count from its level-3 slab; inverse-CDF draw in index order with the caller's
+//             uniform (slice, then chunk, then token) + the sequence's bookkeeping
+// Histograms: a bin is ONE u64, (count << 44) | sum of the bits below the level's digit -- every p of a bin shares the bits above, so
+// the bin's sum is exactly count * base + ulp * sum(low): integer LDS atomics (tools/micro/lds_atomic_rate.hip: ds_add_f32 0.8
+// lane-ops/ns, ds_add_u64 25), order-independent and exact, so the slices' histograms add up to the same u64 in any order.  A slice
+// writes its 256-bin slab to global memory, the next kernel's workgroups each add the 32 slabs (every workgroup repeats the same walk
+// and reaches the same bin; workgroup 0 records the level's result for the kernels after it -- in a slot of its own, since the other
+// workgroups of the same launch are still reading the previous level's).  Ties at the threshold are kept lowest index first.
+constexpr int SMX_G = 32;                              // vocabulary slices = workgroups per sequence
+constexpr int SMX_NT = 256;                            // threads per workgroup (4 waves); also the widest level's bin count
+constexpr int SMX_NW = SMX_NT / 64;
+constexpr int SMX_U = 24;                              // loads in flight per thread: one batch covers a slice of 6 144 tokens (V <= 196 608)
+constexpr int SMX_LV = 4;
+constexpr int SMX_W[SMX_LV] = {9, 8, 8, 7};            // digit widths, top down: sign|exponent, then 23 mantissa bits
+constexpr int SMX_SH[SMX_LV] = {23, 15, 7, 0};
+constexpr int SMX_NB[SMX_LV] = {128, 256, 256, 128};   // (0 <= p <= 1: the top digit is <= 127)
+constexpr int SMX_CP = 8, SMX_STRIDE = 257;            // LDS copies per lane group (a wave whose lanes all hit one bin must not serialise)
+constexpr int SMX_CNT_SHIFT = 44;                      // V < 2^20 tokens, <= 23-bit `low`: 43 bits of sum
+
+struct SmxLevel { double cum_above; double target; unsigned prefix, mask; };
+struct SmxWs {                                         // per sequence
+  float pmax[SMX_G], psum[SMX_G], pabove[SMX_G];
+  SmxLevel lv[SMX_LV];                                 // lv[l]: the state after walking level l (l = 0 .. 2)
+  unsigned long long slab[SMX_LV][SMX_G][SMX_NT];
+};
+
+struct SmxArgs { float* logits; int V; int32_t* tokens; int32_t* hist; const float* uniforms; LmState* st; SmxWs* ws; mia_lm_sampler sp; int n_prompt; int max_ctx; };
+struct SmxCtx { float* P; int32_t* tokens; int32_t* hist; const float* uniforms; LmState* st; SmxWs* ws; int lo, hi, sl; };
+
+// this workgroup's sequence (blockIdx.y) and slice (blockIdx.x): pointers and bounds only, no memory access
+__device__ __forceinline__ SmxCtx smx_ctx(const SmxArgs& a) {
+  SmxCtx c;
+  const int b = blockIdx.y;
+  c.st = a.st + b; c.P = a.logits + (int64_t)b * a.V; c.tokens = a.tokens + (int64_t)b * a.max_ctx; c.hist = a.hist + b * 64; c.uniforms = a.uniforms + (int64_t)b * a.max_ctx; c.ws = a.ws + b;
+  c.sl = (a.V + SMX_G - 1) / SMX_G;
+  c.lo = min(a.V, (int)blockIdx.x * c.sl); c.hi = min(a.V, c.lo + c.sl);
+  return c;
+}
+// false while the prompt is still being consumed (or the sequence is done): nothing to draw.  (The step graph passes n_prompt = -1 and
+// the state holds it: one graph serves every prompt length.)
+__device__ __forceinline__ bool smx_drawing(const SmxArgs& a, const LmState& s) { return !(s.pos + 1 < (a.n_prompt < 0 ? s.n_prompt : a.n_prompt) || s.finished); }
+__device__ __forceinline__ bool smx_use_top_p(const mia_lm_sampler& sp, int V) { return sp.top_p > 0.0f && sp.top_p < 1.0f && V > 1; }
+
+// one batch of the slice, element u of thread t = token base + t + 256 u; the loads are unconditional (index clamped) so that they are
+// all in flight before anything waits
+__device__ __forceinline__ void smx_load(const float* __restrict__ P, int base, int hi, float (&v)[SMX_U]) {
+  const int last = max(hi - 1, 0);
+#pragma unroll
+  for (int u = 0; u < SMX_U; ++u) v[u] = P[min(base + (int)threadIdx.x + SMX_NT * u, last)];
+}
+template <typename F>
+__device__ __forceinline__ void smx_apply(const float (&v)[SMX_U], int base, int hi, F f) {
+#pragma unroll
+  for (int u = 0; u < SMX_U; ++u) { const int i = base + (int)threadIdx.x + SMX_NT * u; if (i < hi) f(i, v[u], u); }
+}
+// f over the whole slice; v0 = its first batch, already loaded
+template <typename F>
+__device__ __forceinline__ void smx_each(const float* __restrict__ P, int lo, int hi, const float (&v0)[SMX_U], F f) {
+  smx_apply(v0, lo, hi, f);
+  for (int base = lo + SMX_NT * SMX_U; base < hi; base += SMX_NT * SMX_U) { float v[SMX_U]; smx_load(P, base, hi, v); smx_apply(v, base, hi, f); }
+}
+
+template <typename V, int NW>
+__device__ __forceinline__ V blk_excl_scan(V v, V* sh) {   // exclusive prefix over the workgroup in thread order; sh: NW words of scratch
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const V incl = wave_incl_scan(v, lane);
   V excl = __shfl_up(incl, 1, 64);
@@ -432,215 +491,316 @@ __device__ __forceinline__ V blk1024_excl_scan(V v, V* sh) {
   __syncthreads();
   V base = (V)0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) if (i < wave) base += sh[i];
+  for (int i = 0; i < NW; ++i) if (i < wave) base += sh[i];
   return base + excl;
 }
+template <int NW>
+__device__ __forceinline__ float blk_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) r += sh[i];
+  return r;
+}
 
-__global__ __launch_bounds__(1024) void lm_sample(float* __restrict__ logits, int V, int32_t* __restrict__ tokens, int32_t* __restrict__ hist,
-                                                  const float* __restrict__ uniforms, LmState* __restrict__ st, mia_lm_sampler sp, int n_prompt_arg, int max_ctx) {
-  // one workgroup per sequence
-  st += blockIdx.x; logits += (int64_t)blockIdx.x * V; tokens += (int64_t)blockIdx.x * max_ctx; hist += blockIdx.x * 64; uniforms += (int64_t)blockIdx.x * max_ctx;
-  const int n_prompt = n_prompt_arg < 0 ? st->n_prompt : n_prompt_arg;      // the step graph reads it from the state: one graph serves every prompt length
-  extern __shared__ unsigned long long hbin[];                               // per-copy bins, layout per level (see above)
-  __shared__ double shd[16];
-  __shared__ double s_d[2];
-  __shared__ float sh[16];
-  __shared__ int shi[16];
-  __shared__ float s_f[4];
-  __shared__ int s_i[6];
-  __shared__ float wtot[16];
-  __shared__ int wtie[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pos = st->pos;
-  const int cur_len = pos + 1;
-  if (cur_len < n_prompt || st->finished) {            // still consuming the prompt (or done): nothing to draw
-    __syncthreads();
+// value of a bin record: count * (smallest member) + ulp * sum(low bits), exact in double
+__device__ __forceinline__ double smx_bin_value(unsigned long long h, unsigned bits) {
+  constexpr unsigned long long ONE = 1ull << SMX_CNT_SHIFT;
+  const int e = max((int)((bits >> 23) & 0xffu), 1);
+  const double ulp = __longlong_as_double((long long)(e - 150 + 1023) << 52);       // 2^(e - 150)
+  return (double)(h >> SMX_CNT_SHIFT) * (double)__uint_as_float(bits) + (double)(h & (ONE - 1ull)) * ulp;
+}
+
+__device__ __forceinline__ void smx_hist_clear(unsigned long long* hb) {
+  for (int i = threadIdx.x; i < SMX_CP * SMX_STRIDE; i += SMX_NT) hb[i] = 0ull;
+}
+template <int LVL>
+__device__ __forceinline__ void smx_hist_put(unsigned long long* hb, float p, unsigned prefix, unsigned mask) {
+  constexpr unsigned long long ONE = 1ull << SMX_CNT_SHIFT;
+  constexpr int shf = SMX_SH[LVL], nb = SMX_NB[LVL];
+  constexpr unsigned dmask = (1u << SMX_W[LVL]) - 1u, lmask = (1u << shf) - 1u;
+  const unsigned b = __float_as_uint(p);
+  if ((b & mask) != prefix) return;
+  const int bin = min((int)((b >> shf) & dmask), nb - 1);
+  atomicAdd(&hb[(threadIdx.x & (SMX_CP - 1)) * SMX_STRIDE + bin], ONE | (unsigned long long)(b & lmask));
+}
+// the slice's 256-bin slab to global memory (every bin written: no zeroing pass)
+template <int LVL>
+__device__ __forceinline__ void smx_hist_store(const SmxCtx& c, const unsigned long long* hb) {
+  unsigned long long h = 0ull;
+  if ((int)threadIdx.x < SMX_NB[LVL]) {
+#pragma unroll
+    for (int r = 0; r < SMX_CP; ++r) h += hb[r * SMX_STRIDE + threadIdx.x];
+  }
+  c.ws->slab[LVL][blockIdx.x][threadIdx.x] = h;
+}
+
+// Walk level LVL's merged histogram from the largest bin down until the cumulative sum crosses the target, as a workgroup-wide prefix
+// sum: thread t owns descending position t (bin nb-1-t) and has the merged record h of its bin.  Returns the state after the level
+// (identical in every thread of every workgroup of the launch); sel_bin = the bin it settled on.
+template <int LVL>
+__device__ __forceinline__ SmxLevel smx_walk(unsigned long long h, SmxLevel in, double* shd, int* s_i, double* s_d, int* sel_bin = nullptr) {
+  constexpr int shf = SMX_SH[LVL], nb = SMX_NB[LVL];
+  constexpr unsigned dmask = (1u << SMX_W[LVL]) - 1u;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_i[0] = 0x7fffffff; s_i[1] = -1; }
+  const int bin = nb - 1 - tid;
+  const bool occ = bin >= 0 && (h >> SMX_CNT_SHIFT) != 0ull;
+  const double a = occ ? smx_bin_value(h, in.prefix | ((unsigned)bin << shf)) : 0.0;
+  const double before = in.cum_above + blk_excl_scan<double, SMX_NW>(a, shd);      // (its barriers publish s_i's reset)
+  if (occ && before + a > in.target) atomicMin(&s_i[0], tid);
+  if (occ) atomicMax(&s_i[1], tid);
+  __syncthreads();
+  // never crossed (rounding corner): settle on the lowest occupied bin
+  const int sel_r = s_i[0] != 0x7fffffff ? s_i[0] : max(s_i[1], 0);
+  if (tid == sel_r) s_d[0] = before;
+  __syncthreads();
+  SmxLevel out = in;
+  out.cum_above = s_d[0];
+  out.prefix = in.prefix | (((unsigned)(nb - 1 - sel_r)) << shf);
+  out.mask = in.mask | (dmask << shf);
+  if (sel_bin) *sel_bin = nb - 1 - sel_r;
+  __syncthreads();
+  return out;
+}
+// thread t's merged record of bin nb-1-t: the 32 slices' slabs added up (all loads in flight at once)
+template <int LVL>
+__device__ __forceinline__ unsigned long long smx_merged(const SmxWs* ws) {
+  const int bin = SMX_NB[LVL] - 1 - (int)threadIdx.x;
+  const unsigned long long* sl = &ws->slab[LVL][0][max(bin, 0)];
+  unsigned long long r[SMX_G];
+#pragma unroll
+  for (int g = 0; g < SMX_G; ++g) r[g] = sl[(size_t)g * SMX_NT];
+  unsigned long long h = 0ull;
+#pragma unroll
+  for (int g = 0; g < SMX_G; ++g) h += r[g];
+  return h;
+}
+
+__global__ __launch_bounds__(SMX_NT) void smx_max(SmxArgs a) {
+  const SmxCtx c = smx_ctx(a);
+  __shared__ float sh[SMX_NW];
+  __shared__ int pen_tok[64];
+  __shared__ float pen_val[64];
+  __shared__ int n_pen;
+  const int tid = threadIdx.x;
+  float v0[SMX_U];
+  smx_load(c.P, c.lo, c.hi, v0);
+  const LmState s = *c.st;
+  const int htok = tid < 64 ? c.hist[tid] : -1;
+  if (tid == 0) n_pen = 0;
+  if (!smx_drawing(a, s)) return;
+  // 1. repetition penalty over the last `rep_window` generated tokens (gather all, then scatter: duplicates penalised once); a token
+  //    lies in exactly one slice.  The slice is already in registers: the penalised values are patched in through a short LDS list
+  __syncthreads();
+  if (a.sp.rep_penalty != 1.0f && tid < s.n_hist && htok >= c.lo && htok < c.hi) {
+    const float gth = c.P[htok];
+    const float upd = gth < 0.f ? gth * a.sp.rep_penalty : gth / a.sp.rep_penalty;
+    const int k = atomicAdd(&n_pen, 1);
+    pen_tok[k] = htok; pen_val[k] = upd;
+  }
+  __syncthreads();
+  const int np = n_pen;
+  if (tid < np) c.P[pen_tok[tid]] = pen_val[tid];        // (duplicates write the same value)
+  float mx = -INFINITY;
+  smx_each(c.P, c.lo, c.hi, v0, [&](int i, float z, int) {
+    for (int k = 0; k < np; ++k) z = pen_tok[k] == i ? pen_val[k] : z;
+    mx = fmaxf(mx, z);
+  });
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) sh[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    float r = sh[0];
+    for (int i = 1; i < SMX_NW; ++i) r = fmaxf(r, sh[i]);
+    c.ws->pmax[blockIdx.x] = r * (1.0f / fmaxf(a.sp.temperature, 1e-6f));      // (T > 0: the maximum commutes with the scaling)
+  }
+}
+
+__global__ __launch_bounds__(SMX_NT) void smx_exp(SmxArgs a) {
+  const SmxCtx c = smx_ctx(a);
+  __shared__ unsigned long long hb[SMX_CP * SMX_STRIDE];
+  __shared__ float sh[SMX_NW];
+  const int tid = threadIdx.x;
+  float v0[SMX_U];
+  smx_load(c.P, c.lo, c.hi, v0);
+  float mx = c.ws->pmax[tid & (SMX_G - 1)];
+  const LmState s = *c.st;
+  if (!smx_drawing(a, s)) return;
+  const bool use_top_p = smx_use_top_p(a.sp, a.V);
+  smx_hist_clear(hb);
+#pragma unroll
+  for (int o = 1; o < SMX_G; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float inv_t = 1.0f / fmaxf(a.sp.temperature, 1e-6f);
+  __syncthreads();
+  // 2. the unnormalised probabilities p = exp(z / T - max) REPLACE the logits (the buffer is rewritten by the next step's head GEMM),
+  //    so every later kernel reads the same p without another exp
+  float tot = 0.f;
+  smx_each(c.P, c.lo, c.hi, v0, [&](int i, float z, int) {
+    const float p = __expf(z * inv_t - mx);
+    c.P[i] = p; tot += p;
+    if (use_top_p) smx_hist_put<0>(hb, p, 0u, 0u);
+  });
+  tot = blk_sum<SMX_NW>(tot, sh);                        // (its barriers also complete the histogram)
+  if (tid == 0) c.ws->psum[blockIdx.x] = tot;
+  if (use_top_p) smx_hist_store<0>(c, hb);
+}
+
+template <int LVL>      // 1 .. 3: walk level LVL-1, histogram level LVL
+__global__ __launch_bounds__(SMX_NT) void smx_level(SmxArgs a) {
+  const SmxCtx c = smx_ctx(a);
+  if (!smx_use_top_p(a.sp, a.V)) return;
+  __shared__ unsigned long long hb[SMX_CP * SMX_STRIDE];
+  __shared__ double shd[SMX_NW];
+  __shared__ double s_d[1];
+  __shared__ int s_i[2];
+  __shared__ float sh[SMX_NW];
+  const int tid = threadIdx.x;
+  float v0[SMX_U];
+  smx_load(c.P, c.lo, c.hi, v0);
+  const unsigned long long h = smx_merged<LVL - 1>(c.ws);
+  SmxLevel in;
+  if constexpr (LVL == 1) {
+    float ps = c.ws->psum[tid & (SMX_G - 1)];
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < SMX_G; ++g) tot += __shfl(ps, g, 64);               // slice order: the same total in every workgroup
+    in.cum_above = 0.0; in.target = (double)(a.sp.top_p * tot);             // the descending cumulative sum must EXCEED this
+    in.prefix = 0u; in.mask = 0u;
+  } else in = c.ws->lv[LVL - 2];
+  const LmState s = *c.st;
+  if (!smx_drawing(a, s)) return;
+  smx_hist_clear(hb);
+  const SmxLevel out = smx_walk<LVL - 1>(h, in, shd, s_i, s_d);           // (its barriers publish the cleared histogram)
+  if (blockIdx.x == 0 && tid == 0) c.ws->lv[LVL - 1] = out;
+  float above = 0.f;
+  smx_each(c.P, c.lo, c.hi, v0, [&](int, float p, int) {
+    smx_hist_put<LVL>(hb, p, out.prefix, out.mask);
+    if (LVL == SMX_LV - 1 && (__float_as_uint(p) & out.mask) > out.prefix) above += p;
+  });
+  if (LVL == SMX_LV - 1) { above = blk_sum<SMX_NW>(above, sh); if (tid == 0) c.ws->pabove[blockIdx.x] = above; }
+  else __syncthreads();
+  smx_hist_store<LVL>(c, hb);
+}
+
+// 4. the last level's walk, then the inverse-CDF draw over the kept tokens in index order with the caller's uniform: serial over the 32
+//    slices, then the whole workgroup resolves the selected slice (thread t owns CH contiguous tokens, a prefix sum finds the first
+//    chunk that crosses the goal and its thread walks it in index order)
+__global__ __launch_bounds__(SMX_NT) void smx_draw(SmxArgs a) {
+  const SmxCtx c = smx_ctx(a);                            // gridDim.x = 1: lo / hi are not used here
+  LmState* st = c.st;
+  const int tid = threadIdx.x, lane = tid & 63;
+  constexpr int L3 = SMX_LV - 1, NB3 = SMX_NB[L3];
+  __shared__ double shd[SMX_NW];
+  __shared__ double s_d[1];
+  __shared__ float sh[SMX_NW];
+  __shared__ int shi[SMX_NW];
+  __shared__ float s_f[3];
+  __shared__ int s_i[5];
+  __shared__ unsigned long long part[SMX_NT];
+  __shared__ float pkeep[SMX_G];
+  __shared__ int ptie[SMX_G];
+  __shared__ float slice[SMX_NT * SMX_U];
+  const bool use_top_p = smx_use_top_p(a.sp, a.V);
+  // level-3 records: thread t holds bin (t & 127) of the slices 16 (t >> 7) .. + 15 -- for the merged walk AND for the per-slice sums
+  const int my_bin = tid & (NB3 - 1), g0 = (tid >> 7) * (SMX_G / 2);
+  unsigned long long rec[SMX_G / 2];
+#pragma unroll
+  for (int g = 0; g < SMX_G / 2; ++g) rec[g] = use_top_p ? c.ws->slab[L3][g0 + g][my_bin] : 0ull;
+  const float ps = c.ws->psum[tid & (SMX_G - 1)], pa = c.ws->pabove[tid & (SMX_G - 1)];
+  SmxLevel in = c.ws->lv[L3 - 1];
+  const LmState s = *st;
+  const int pos = s.pos, cur_len = pos + 1;
+  if (!smx_drawing(a, s)) {                               // still consuming the prompt (or done): nothing to draw
     if (tid == 0) st->pos = pos + 1;
     return;
   }
-  const int n_hist = st->n_hist;
-  // 1. repetition penalty over the last `rep_window` generated tokens (gather all, then scatter: duplicates penalised once)
-  if (sp.rep_penalty != 1.0f && n_hist > 0) {
-    float upd = 0.f; int tok = -1;
-    if (tid < n_hist) { tok = hist[tid]; const float gth = logits[tok]; upd = gth < 0.f ? gth * sp.rep_penalty : gth / sp.rep_penalty; }
-    __syncthreads();
-    if (tid < n_hist) logits[tok] = upd;
-    __syncthreads();
-  }
-  const float inv_t = 1.0f / fmaxf(sp.temperature, 1e-6f);
-  const int nv4 = V >> 2, tail0 = nv4 << 2;            // float4 body + scalar tail
-  f32x4* l4 = reinterpret_cast<f32x4*>(logits);
-  // 2. softmax statistics of the temperature-scaled logits; the unnormalised probabilities p = exp(z - max) REPLACE the logits
-  //    (the buffer is rewritten by the next step's head GEMM), so every later pass reads the same p without another exp
-  float mx = -INFINITY;
-  for (int i = tid; i < nv4; i += 8192) {              // the logits were written by other XCDs: eight 16-byte misses in flight per lane
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { const int k = i + 1024 * u; v[u] = l4[k < nv4 ? k : i]; }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) mx = fmaxf(fmaxf(mx, fmaxf(v[u][0], v[u][1]) * inv_t), fmaxf(v[u][2], v[u][3]) * inv_t);
-  }
-  if (tail0 + tid < V) mx = fmaxf(mx, logits[tail0 + tid] * inv_t);
-  mx = blk1024_max(mx, sh);
-  float tot = 0.f;
-  for (int i = tid; i < nv4; i += 4096) {
-    f32x4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int k = i + 1024 * u; v[u] = l4[k < nv4 ? k : i]; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (i + 1024 * u < nv4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[u][j] = __expf(v[u][j] * inv_t - mx);
-        l4[i + 1024 * u] = v[u];
-        tot += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
-      }
-  }
-  if (tail0 + tid < V) { const float p = __expf(logits[tail0 + tid] * inv_t - mx); logits[tail0 + tid] = p; tot += p; }
-  tot = blk1024_sum(tot, sh);                          // (its barriers also publish the p stores to the whole workgroup)
-  const float* __restrict__ P = logits;
-  const f32x4* __restrict__ P4 = reinterpret_cast<const f32x4*>(logits);
-  // 3. top-p: find the bit pattern of the smallest kept probability by a 3-level radix select (11 | 11 | 10 bits, top down)
+  const float u01 = c.uniforms[s.n_gen];
   unsigned thr_bits = 0u;        // keep p > thr, plus `keep_ties` of the p == thr (lowest index first)
   int keep_ties = 0x7fffffff;
-  const bool use_top_p = sp.top_p > 0.0f && sp.top_p < 1.0f && V > 1;
   if (use_top_p) {
-    const double target = (double)(sp.top_p * tot);   // cumulative (descending) sum must EXCEED this
-    unsigned prefix = 0u, mask = 0u;                  // bits fixed so far
-    double cum_above = 0.0;                           // sum of probabilities strictly above the current candidate range
-#pragma unroll 1
-    for (int lvl = 0; lvl < 3; ++lvl) {
-      constexpr unsigned long long ONE = 1ull << SMP_CNT_SHIFT;
-      const int shf = SMP_SH[lvl], nb = SMP_NB[lvl], n_copies = SMP_CP[lvl], stride = SMP_ST[lvl];
-      const unsigned dmask = (1u << SMP_W[lvl]) - 1u, lmask = (1u << shf) - 1u;
-      const int cpy = (lane & (n_copies - 1)) * stride;
-      for (int i = tid; i < n_copies * stride; i += 1024) hbin[i] = 0ull;
-      if (tid == 0) { s_i[0] = 0x7fffffff; s_i[1] = -1; }
-      __syncthreads();
-      auto put = [&](float p) {
-        const unsigned b = __float_as_uint(p);
-        if ((b & mask) != prefix) return;
-        const int bin = min((int)((b >> shf) & dmask), nb - 1);               // (top level: 0 <= p <= 1 -> digit <= 127)
-        atomicAdd(&hbin[cpy + bin], ONE | (unsigned long long)(b & lmask));
-      };
-      for (int i = tid; i < nv4; i += 4096) {          // four independent 16-byte loads in flight per lane
-        f32x4 v[4];
+    unsigned long long hsum = 0ull;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int k = i + 1024 * u; v[u] = P4[k < nv4 ? k : i]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (i + 1024 * u < nv4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) put(v[u][j]);
-          }
-      }
-      if (tail0 + tid < V) put(P[tail0 + tid]);
-      __syncthreads();
-      // walk from the largest bin down until the target is crossed -- as a workgroup-wide prefix sum: thread t owns the PER
-      // descending positions PER*t .. PER*t + PER-1 (position r <-> bin nb-1-r); copies are merged in registers
-      constexpr int PER = 4;                           // 4096 bins / 1024 threads at the widest level
-      double a[PER]; bool occ[PER]; double mine = 0.0;
-#pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        const int bin = nb - 1 - (PER * tid + j);
-        a[j] = 0.0; occ[j] = false;
-        if (bin >= 0) {
-          unsigned long long h = 0ull;
-          for (int r = 0; r < n_copies; ++r) h += hbin[r * stride + bin];
-          const unsigned bits = prefix | ((unsigned)bin << shf);               // smallest member of the bin
-          const int e = (int)((bits >> 23) & 0xffu);
-          const double ulp = ldexp(1.0, max(e, 1) - 150);
-          const double cnt = (double)(h >> SMP_CNT_SHIFT), low = (double)(h & (ONE - 1ull));
-          a[j] = cnt * (double)__uint_as_float(bits) + low * ulp;
-          occ[j] = (h >> SMP_CNT_SHIFT) != 0ull;
-        }
-        mine += a[j];
-      }
-      double before = cum_above + blk1024_excl_scan<double>(mine, shd);
-      int hit = -1, lowest = -1; double before_hit = 0.0, before_low = 0.0;
-#pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        if (occ[j]) { lowest = PER * tid + j; before_low = before; if (hit < 0 && before + a[j] > target) { hit = PER * tid + j; before_hit = before; } }
-        before += a[j];
-      }
-      if (hit >= 0) atomicMin(&s_i[0], hit);
-      if (lowest >= 0) atomicMax(&s_i[1], lowest);
-      __syncthreads();
-      // never crossed (rounding corner): settle on the lowest occupied bin
-      const bool crossed = s_i[0] != 0x7fffffff;
-      const int sel_r = crossed ? s_i[0] : max(s_i[1], 0);
-      if (crossed ? hit == sel_r : lowest == sel_r) s_d[0] = crossed ? before_hit : before_low;
-      __syncthreads();
-      cum_above = s_d[0];
-      prefix |= ((unsigned)(nb - 1 - sel_r)) << shf;
-      mask |= dmask << shf;
-      __syncthreads();
-    }
-    thr_bits = prefix;
+    for (int g = 0; g < SMX_G / 2; ++g) hsum += rec[g];
+    part[tid] = hsum;
+    __syncthreads();
+    const int wb = NB3 - 1 - tid;                         // the walk wants bin nb-1-t in thread t
+    const unsigned long long h = wb >= 0 ? part[wb] + part[wb + NB3] : 0ull;
+    int sel_bin = 0;
+    const SmxLevel out = smx_walk<L3>(h, in, shd, s_i, s_d, &sel_bin);
+    thr_bits = out.prefix;
     const float thr = __uint_as_float(thr_bits);
     // ties: keep the smallest k >= 1 with cum_above + k*thr > target
     int k = 1;
-    if (thr > 0.f) { const double need = (target - cum_above) / (double)thr; k = need >= 2.0e9 ? 0x7fffffff : (int)floor(need) + 1; if (k < 1) k = 1; }
+    if (thr > 0.f) { const double need = (out.target - out.cum_above) / (double)thr; k = need >= 2.0e9 ? 0x7fffffff : (int)floor(need) + 1; if (k < 1) k = 1; }
     keep_ties = k;
-  }
-  // 4. inverse-CDF draw over the kept tokens in index order with the caller's uniform.
-  //    a) each wave sums the kept probabilities of one contiguous sixteenth of the vocabulary (coalesced float4 loads)
+    // every slice's kept sum = what lies above the level-3 bin range + its bins above the selected one; its ties = the selected bin's count
+    // (thread (g, j) adds bins 16 j .. 16 j + 15 of slice g from LDS)
+    __shared__ unsigned long long recs[SMX_G][NB3 + 1];
+#pragma unroll
+    for (int g = 0; g < SMX_G / 2; ++g) recs[g0 + g][my_bin] = rec[g];
+    __syncthreads();
+    const int g = tid >> 3, j = tid & 7;
+    const float pag = __shfl(pa, g & 31, 64);             // pabove[g] (lane l holds slice l & 31; every lane takes part in the shuffle)
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NB3 / 8; ++q) {
+      const int bin = j * (NB3 / 8) + q;
+      const unsigned long long r = recs[g][bin];
+      if (bin > sel_bin && (r >> SMX_CNT_SHIFT) != 0ull) acc += smx_bin_value(r, in.prefix | (unsigned)bin);
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+    if (j == 0) { pkeep[g] = pag + (float)acc; ptie[g] = (int)(recs[g][sel_bin] >> SMX_CNT_SHIFT); }
+  } else if (tid < SMX_G) { pkeep[tid] = ps; ptie[tid] = 0; }
+  __syncthreads();
   const float thr = __uint_as_float(thr_bits);
-  const int per_wave = (((V + 15) / 16) + 3) & ~3;
-  const int w_lo = min(V, wave * per_wave), w_hi = min(V, w_lo + per_wave);
-  {
-    float wsum = 0.f; int wt = 0;
-    auto acc = [&](float p) {
-      const unsigned b = __float_as_uint(p);
-      if (!use_top_p || b > thr_bits) wsum += p; else if (b == thr_bits) ++wt;
-    };
-    const int n4 = (w_hi - w_lo) >> 2;
-    for (int i = lane; i < n4; i += 256) {
-      f32x4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int k = i + 64 * u; v[u] = *reinterpret_cast<const f32x4*>(P + w_lo + 4 * (k < n4 ? k : i)); }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) if (i + 64 * u < n4) { acc(v[u][0]); acc(v[u][1]); acc(v[u][2]); acc(v[u][3]); }
-    }
-    if (w_lo + 4 * n4 + lane < w_hi) acc(P[w_lo + 4 * n4 + lane]);
-    wsum = wave_sum(wsum);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wt += __shfl_xor(wt, o, 64);
-    if (lane == 0) { wtot[wave] = wsum; wtie[wave] = wt; }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    // b) serial over the 16 ranges: the kept total, then the range holding the goal (ties count lowest index first, up to keep_ties)
-    int nt = 0; float ks = 0.f;
-    for (int w2 = 0; w2 < 16; ++w2) { nt += wtie[w2]; ks += wtot[w2]; }
+  const float* __restrict__ P = c.P;
+  if (tid < 64) {
+    // the kept total, then the slice holding the goal (ties count lowest index first, up to keep_ties): prefix sums over the 32 slices
+    // in lanes 0 .. 31 of the first wave (fixed order: deterministic)
+    const bool on = lane < SMX_G;
+    const int my_tie = on ? ptie[lane] : 0;
+    const float my_keep = on ? pkeep[lane] : 0.f;
+    const int tie_incl = wave_incl_scan(my_tie, lane);
+    const int nt = __shfl(tie_incl, 63, 64);
     const int kt = use_top_p ? min(keep_ties, nt) : 0;
-    const float goal = uniforms[st->n_gen] * (ks + (float)kt * thr);
-    float cum = 0.f; int used = 0, sel = -1, last = 0; float cum_last = 0.f; int used_last = 0;
-    for (int w2 = 0; w2 < 16; ++w2) {
-      const int tk = min(wtie[w2], max(0, kt - used));
-      const float add = wtot[w2] + (float)tk * thr;
-      if (add > 0.f) { last = w2; cum_last = cum; used_last = used; }
-      if (cum + add > goal) { sel = w2; break; }
-      cum += add; used += tk;
-    }
-    if (sel < 0) { sel = last; cum = cum_last; used = used_last; }        // goal >= kept total (rounding): last range that holds anything
-    s_f[1] = cum; s_f[2] = goal; s_i[1] = sel; s_i[2] = used; s_i[3] = kt; s_i[0] = 0x7fffffff; s_i[4] = -1;
+    const int used = min(kt, tie_incl - my_tie);          // ties already used by the slices before this one
+    const int tk = min(my_tie, kt - used);
+    const float add = my_keep + (float)tk * thr;
+    const float add_incl = wave_incl_scan(add, lane);
+    const float goal = u01 * __shfl(add_incl, 63, 64);
+    const float cum = add_incl - add;
+    const unsigned long long crosses = __ballot(on && cum + add > goal), holds = __ballot(on && add > 0.f);
+    // goal >= kept total (rounding): the last slice that holds anything
+    const int sel = crosses ? __ffsll((long long)crosses) - 1 : (holds ? 63 - __clzll((long long)holds) : 0);
+    if (lane == sel) { s_f[1] = cum; s_f[2] = goal; s_i[1] = sel; s_i[2] = used; s_i[3] = kt; s_i[0] = 0x7fffffff; s_i[4] = -1; }
   }
   __syncthreads();
-  // c) the whole workgroup resolves the selected range: thread t owns CH contiguous tokens, a workgroup-wide prefix sum finds the
-  //    first thread whose chunk crosses the goal, and that thread walks its chunk in index order
   const int sel = s_i[1], kt = s_i[3], ties0 = s_i[2];
   const float cum0 = s_f[1], goal = s_f[2];
-  const int r_lo = min(V, sel * per_wave), r_hi = min(V, r_lo + per_wave);
-  const int CH = (per_wave + 1023) / 1024;
+  const int r_lo = min(a.V, sel * c.sl), r_hi = min(a.V, r_lo + c.sl);
+  // the selected slice through LDS (coalesced, all loads in flight), then thread t reads its own contiguous chunk
+  const bool staged = c.sl <= SMX_NT * SMX_U;
+  if (staged) {
+    float v[SMX_U];
+    smx_load(P, r_lo, r_hi, v);
+#pragma unroll
+    for (int u = 0; u < SMX_U; ++u) slice[tid + SMX_NT * u] = v[u];
+  }
+  __syncthreads();
+  auto at = [&](int i) { return staged ? slice[i - r_lo] : P[i]; };
+  const int CH = (c.sl + SMX_NT - 1) / SMX_NT;
   const int t_lo = min(r_hi, r_lo + tid * CH), t_hi = min(r_hi, t_lo + CH);
   float tsum = 0.f; int tt = 0; bool any_kept = false;
   for (int i = t_lo; i < t_hi; ++i) {
-    const float p = P[i]; const unsigned b = __float_as_uint(p);
+    const float p = at(i); const unsigned b = __float_as_uint(p);
     if (!use_top_p || b > thr_bits) { tsum += p; any_kept = any_kept || p > 0.f; } else if (b == thr_bits) ++tt;
   }
-  const float ex_sum = blk1024_excl_scan<float>(tsum, sh);
-  const int ex_tie = blk1024_excl_scan<int>(tt, shi);
+  const float ex_sum = blk_excl_scan<float, SMX_NW>(tsum, sh);
+  const int ex_tie = blk_excl_scan<int, SMX_NW>(tt, shi);
   const int used_before = min(kt, ties0 + ex_tie), used_after = min(kt, ties0 + ex_tie + tt);
   const float before = cum0 + ex_sum + (float)(used_before - ties0) * thr;
   const float after = cum0 + (ex_sum + tsum) + (float)(used_after - ties0) * thr;
@@ -652,36 +812,41 @@ __global__ __launch_bounds__(1024) void lm_sample(float* __restrict__ logits, in
     int found = -1, last_kept = -1;
     float cum = before; int used = used_before;
     for (int i = t_lo; i < t_hi && found < 0; ++i) {
-      const float p = P[i]; const unsigned b = __float_as_uint(p);
+      const float p = at(i); const unsigned b = __float_as_uint(p);
       float kv = 0.f;
       if (!use_top_p || b > thr_bits) kv = p;
       else if (b == thr_bits && used < kt) { kv = thr; ++used; }
       if (kv > 0.f) { last_kept = i; if (cum + kv > goal) found = i; cum += kv; }
     }
-    if (found < 0) found = last_kept >= 0 ? last_kept : min(r_lo, V - 1);
+    if (found < 0) found = last_kept >= 0 ? last_kept : min(r_lo, a.V - 1);
     const int next = found;
-    const int ng = st->n_gen;
-    if (cur_len < max_ctx) tokens[cur_len] = next;
+    const int ng = s.n_gen;
+    if (cur_len < a.max_ctx) c.tokens[cur_len] = next;
     st->n_gen = ng + 1;
     bool stop = false;
-    for (int k = 0; k < sp.n_stop; ++k) stop = stop || next == sp.stop_ids[k];
-    if (!stop && sp.rep_window > 0) {                  // history is updated only for non-stop tokens (OrpheusTTS.swift:304-326)
-      int nh = st->n_hist;
-      if (nh < sp.rep_window) { hist[nh] = next; st->n_hist = nh + 1; }
-      else { for (int k = 1; k < nh; ++k) hist[k - 1] = hist[k]; hist[nh - 1] = next; }
+    for (int k = 0; k < a.sp.n_stop; ++k) stop = stop || next == a.sp.stop_ids[k];
+    if (!stop && a.sp.rep_window > 0) {                  // history is updated only for non-stop tokens (OrpheusTTS.swift:304-326)
+      int nh = s.n_hist;
+      if (nh < a.sp.rep_window) { c.hist[nh] = next; st->n_hist = nh + 1; }
+      else { for (int k = 1; k < nh; ++k) c.hist[k - 1] = c.hist[k]; c.hist[nh - 1] = next; }
     }
-    if (stop || ng + 1 >= sp.max_new_tokens || cur_len + 1 >= max_ctx) st->finished = 1;
+    if (stop || ng + 1 >= a.sp.max_new_tokens || cur_len + 1 >= a.max_ctx) st->finished = 1;
     st->pos = pos + 1;
   }
+  (void)lane;
 }
 
-// lm_sample needs 128 KB of dynamic LDS: raise the kernel's limit once per process
-int lm_sample_launch(hipStream_t s, float* logits, int V, int32_t* tokens, int32_t* hist, const float* uniforms, LmState* st, const mia_lm_sampler& sp, int n_prompt, int max_ctx,
-                     int B = 1) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lm_sample), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMP_LDS_BYTES);
-  if (attr != hipSuccess) return -1;
-  hipLaunchKernelGGL(lm_sample, dim3(B), dim3(1024), SMP_LDS_BYTES, s, logits, V, tokens, hist, uniforms, st, sp, n_prompt, max_ctx);
-  return 0;
+// six launches; ws: one SmxWs per sequence
+void lm_sample_launch(hipStream_t s, float* logits, int V, int32_t* tokens, int32_t* hist, const float* uniforms, LmState* st, SmxWs* ws, const mia_lm_sampler& sp,
+                      int n_prompt, int max_ctx, int B = 1) {
+  const dim3 g(SMX_G, B), one(1, B), blk(SMX_NT);
+  const SmxArgs a{logits, V, tokens, hist, uniforms, st, ws, sp, n_prompt, max_ctx};
+  hipLaunchKernelGGL(smx_max, g, blk, 0, s, a);
+  hipLaunchKernelGGL(smx_exp, g, blk, 0, s, a);
+  hipLaunchKernelGGL(smx_level<1>, g, blk, 0, s, a);
+  hipLaunchKernelGGL(smx_level<2>, g, blk, 0, s, a);
+  hipLaunchKernelGGL(smx_level<3>, g, blk, 0, s, a);
+  hipLaunchKernelGGL(smx_draw, one, blk, 0, s, a);
 }
 
 
@@ -1024,7 +1189,7 @@ int lm_enqueue_step(mia_lm* m, bool sampling, const mia_lm_sampler& sp, int n_pr
   const int HV = m->head_vocab > 0 ? m->head_vocab : c.vocab;
   if (skinny(m->h, D, m->lm_head, m->lm_head_f, m->head_bias, m->logits, HV, HV, D, 1, SK_OUTF32, &m->q_head, fused_norm && c.n_layers > 0 ? ss_d : nullptr)) return -1;
   if (ras) hipLaunchKernelGGL(lm_sample_ras, dim3(nb), dim3(1024), 0, s, m->logits, HV, m->tokens, m->out_tokens, m->uniforms, m->state, *ras, c.max_ctx);
-  else if (sampling) { if (lm_sample_launch(s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, sp, n_prompt, c.max_ctx, nb)) return -1; }
+  else if (sampling) lm_sample_launch(s, m->logits, HV, m->tokens, m->hist, m->uniforms, m->state, (SmxWs*)m->smx, sp, n_prompt, c.max_ctx, nb);
   else hipLaunchKernelGGL(lm_advance, dim3(nb), dim3(1), 0, s, m->state);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1166,7 +1331,7 @@ int lm_alloc_state(mia_lm* m, int B) {
   m->ss = (float*)dev((size_t)2 * ((D + 15) / 16) * B * 4);
   m->partial = (float*)dev((size_t)8 * B * D * 4); m->logits = (float*)dev((size_t)B * std::max(c.vocab, m->head_vocab) * 4);
   m->tokens = (int32_t*)dev((size_t)B * c.max_ctx * 4); m->hist = (int32_t*)dev((size_t)B * 64 * 4); m->uniforms = (float*)dev((size_t)B * c.max_ctx * 4);
-  m->state = (LmState*)dev(sizeof(LmState) * B);
+  m->state = (LmState*)dev(sizeof(LmState) * B); m->smx = dev(sizeof(SmxWs) * B);
   m->embeds = (float*)dev((size_t)B * c.max_ctx * D * 4); m->out_tokens = (int32_t*)dev((size_t)B * c.max_ctx * 4);
   if (!ok) return -1;
   (void)hipMemset(m->k_cache, 0, kv); (void)hipMemset(m->v_cache, 0, kv); (void)hipMemset(m->state, 0, sizeof(LmState) * B);
@@ -1601,7 +1766,7 @@ extern "C" int mia_sample_top_p(mia_ctx* ctx, const float* logits, int V, const 
   if (!ctx) return MIA_ERR_INVALID_ARGUMENT;
   MIA_CHECK_ARG(ctx, logits && out && V > 0 && n_hist >= 0 && n_hist <= 64, "sample_top_p: bad arguments");
   MIA_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t need = align_up((size_t)V * 4, 256) + 1024;
+  const size_t need = align_up((size_t)V * 4, 256) + 1024 + sizeof(SmxWs);
   char* ws = (char*)mia_workspace(ctx, need);
   if (!ws) return MIA_ERR_OUT_OF_MEMORY;
   float* d_logits = (float*)ws;
@@ -1610,6 +1775,7 @@ extern "C" int mia_sample_top_p(mia_ctx* ctx, const float* logits, int V, const 
   int32_t* d_hist = (int32_t*)(tail + 64);    // [64]
   float* d_u = (float*)(tail + 64 + 256);
   LmState* d_st = (LmState*)(tail + 64 + 256 + 64);
+  SmxWs* d_smx = (SmxWs*)(tail + 1024);
   LmState st{0, n_hist, 0, 0};
   hipStream_t s = ctx->stream;
   MIA_HIP(ctx, hipMemcpyAsync(d_logits, logits, (size_t)V * 4, hipMemcpyHostToDevice, s));
@@ -1617,7 +1783,7 @@ extern "C" int mia_sample_top_p(mia_ctx* ctx, const float* logits, int V, const 
   MIA_HIP(ctx, hipMemcpyAsync(d_u, &uniform, 4, hipMemcpyHostToDevice, s));
   MIA_HIP(ctx, hipMemcpyAsync(d_st, &st, sizeof(st), hipMemcpyHostToDevice, s));
   mia_lm_sampler sp{}; sp.temperature = temperature; sp.top_p = top_p; sp.rep_penalty = rep_penalty; sp.rep_window = 0; sp.max_new_tokens = 1;
-  if (lm_sample_launch(s, d_logits, V, d_tok, d_hist, d_u, d_st, sp, 1, 2)) return mia_fail(ctx, MIA_ERR_DEVICE, "sample_top_p: cannot reserve LDS");
+  lm_sample_launch(s, d_logits, V, d_tok, d_hist, d_u, d_st, d_smx, sp, 1, 2);
   MIA_HIP(ctx, hipGetLastError());
   MIA_HIP(ctx, hipMemcpyAsync(out, d_tok + 1, 4, hipMemcpyDeviceToHost, s));
   MIA_HIP(ctx, hipStreamSynchronize(s));

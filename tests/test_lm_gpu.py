@@ -105,6 +105,37 @@ def test_top_p_kept_set_size(ctx):
     assert seen == {1}
 
 
+def test_top_p_exact_ties_across_vocabulary_slices(ctx):
+    """Planted ties: four distinct logit values over 9 000 tokens, so the top-p threshold falls INSIDE a group of bit-equal
+    probabilities that spans several of the sampler's 32 vocabulary slices.  The kept part of that group must be its lowest indices
+    (the reference's stable descending sort, OrpheusTTS.swift:417-455): every draw lies in the oracle's kept set and equals the oracle's
+    inverse-CDF draw (a kept set off by one tie would shift the CDF by ~1e-3, ten times the boundary tolerance)."""
+    from mlx_swift_audio_amd import lm as HL
+    rng = np.random.default_rng(12)
+    V = 9000
+    logits = rng.choice(np.array([0.0, 0.7, 1.9, 3.1], np.float32), V, p=[0.55, 0.3, 0.1, 0.05]).astype(np.float32)
+    partial_groups = 0
+    for top_p in (0.35, 0.6, 0.9):
+        f = OL.top_p_filter(logits, [], 1.0, 1.0, top_p)
+        kept = np.isfinite(f)
+        v = logits[kept].min()
+        grp = np.flatnonzero(logits == v)
+        n_kept = int(kept[grp].sum())
+        assert kept[grp[:n_kept]].all() and not kept[grp[n_kept:]].any()       # the oracle keeps a prefix of the tie group
+        partial_groups += 0 < n_kept < grp.size
+        p = np.exp(f.astype(np.float64) - f[kept].max()); p[~kept] = 0
+        c = np.cumsum(p) / p.sum()
+        us = np.concatenate([np.linspace(0.0005, 0.9995, 40), [c[grp[n_kept - 1]] - 1e-5, 1.0 - 1e-6]])    # incl. the last kept tie
+        for u in us:
+            got = HL.sample_next_token(ctx, logits, [], float(u), 1.0, top_p, 1.0)
+            assert kept[got], (top_p, u, got)
+            ref = OL.sample_with_uniform(f, float(u))
+            if got != ref:
+                lo = c[got - 1] if got > 0 else 0.0
+                assert abs(u - lo) < 1e-4 or abs(u - c[got]) < 1e-4, (top_p, u, got, ref)
+    assert partial_groups >= 2
+
+
 @pytest.mark.parametrize("cfg_name", ["llama-micro", "qwen-micro"])
 def test_generate_matches_oracle(ctx, cfg_name):
     from mlx_swift_audio_amd import lm as HL
