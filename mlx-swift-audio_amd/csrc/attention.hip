@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(const uint16_t* _
   // One K/V tile.  TAIL (the last, partial tile only) masks the keys at or beyond T_len: in the full tiles the masking selects are
   // not compiled at all (as a runtime `if (tail)` hipcc if-converted them into ~170 of the tile's ~480 instructions, every tile).
   // The softmax works on the RAW scores: max over s, then p = exp2(fma(s, c, -m c)) with c = scale * log2(e) > 0 -- one fma + one
-  // exp per score instead of mul, sub, exp; the running max is kept raw.
+  // exp per score instead of mul, sub, exp; the reference point m is kept raw.
   auto tile = [&](int kt, int cur, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
     const int key0 = kt * KV_TILE;
@@ -131,10 +131,23 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(const uint16_t* _
         mloc = fmaxf(mloc, acc_s[kb][r]);
       }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);                   // raw (unscaled) running max; every tile holds >= 1 valid key
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);
-    const float neg_mc = -m_new * scale_log2;
-    m_run = m_new;
+    // Bounded-growth lazy rescaling: the reference point m_run of a query moves only when the tile's maximum exceeds it by more than
+    // 2^LAZY_LOG2 (in the exponent's units), so p = exp2(c (s - m_run)) <= 2^LAZY_LOG2 and the O / l rescale -- 32 multiplies + one exp
+    // per tile, ~12 % of the loop's vector issue -- runs in the first tile and then almost never (softmax is invariant to the reference
+    // point; the 16-bit P keeps its relative precision at any scale, O and l accumulate in fp32).  The test is wave-uniform.
+    constexpr float LAZY_LOG2 = 8.0f;
+    const bool grow = (mloc - m_run) * scale_log2 > LAZY_LOG2;   // first tile: m_run = -inf; every tile holds >= 1 valid key
+    if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+      const float m_new = grow ? mloc : m_run;
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);       // 1 for the lanes that stay
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+    }
+    const float neg_mc = -m_run * scale_log2;
     // (pairing the scores through v_pk_fma_f32 / v_pk_add_f32 was measured: 231 instead of 256 instructions per tile, 16.5-16.6 ms
     // per pass against 16.3-16.4 in alternating runs on one box -- the packed fp32 ops are not double rate here)
     float lsum = 0.f;
@@ -155,11 +168,7 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(const uint16_t* _
         pf[kb][s] = __builtin_bit_cast(s16x8, w);
       }
     }
-    l_run = l_run * alpha + lsum;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+    l_run += lsum;
 
     // ---- O^T += V^T P^T
 #pragma unroll
