@@ -469,6 +469,28 @@ def codec_bench(ctx, torch):
     ms = e0.elapsed_time(e1) / reps
     res["hift_cosyvoice2_vocode"] = {"samples_per_s": round(h_out / (ms * 1e-3), 0), "ms": round(ms, 3), "samples": h_out,
                                      "realtime_factor": round(h_out / 24000.0 / (ms * 1e-3), 1), **alg(run_hift, ms)}
+    # the same utterance x 8 in one stacked call (mia_hift_vocode_batch: every convolution once over 8 sequences)
+    NB = 8
+    mel8 = mel.unsqueeze(0).repeat(NB, 1, 1).contiguous()
+    noise8 = hnoise.unsqueeze(0).repeat(NB, 1, 1).contiguous()
+    pcm8 = torch.empty(NB * h_out, device="cuda")
+    T8 = np.full(NB, T, np.int32)
+
+    def run_hift8():
+        ctx.check(ctx.lib.mia_hift_vocode_batch(hg.h, mel8.data_ptr(), T8.ctypes.data, NB, noise8.data_ptr(), pcm8.data_ptr(), 1))
+
+    for _ in range(2):
+        run_hift8()
+    e0.record()
+    for _ in range(reps):
+        run_hift8()
+    e1.record()
+    torch.cuda.synchronize()
+    ms8 = e0.elapsed_time(e1) / reps
+    same = bool(torch.equal(pcm8.view(NB, h_out)[NB - 1], hpcm)) and bool(torch.equal(pcm8.view(NB, h_out)[0], hpcm))
+    res["hift_cosyvoice2_vocode_batch8"] = {"samples_per_s": round(NB * h_out / (ms8 * 1e-3), 0), "ms": round(ms8, 3), "utterances": NB,
+                                            "ms_per_utterance": round(ms8 / NB, 3), "realtime_factor": round(NB * h_out / 24000.0 / (ms8 * 1e-3), 1),
+                                            "equals_single_call": same}
     hg.close()
     # ---- CosyVoice2 flow: 375 new + 150 prompt speech tokens (15 s + 6 s) -> 750 new mel frames, 10 Euler steps with CFG
     from mlx_swift_audio_amd import flow as HFL

@@ -468,6 +468,13 @@ int mia_hift_decode(mia_hift* h, const float* mel, int T, const float* source, f
  * with MIA_MEM_DEVICE nothing is copied and the call returns after enqueueing on the ctx stream. */
 int mia_hift_vocode(mia_hift* h, const float* mel, int T, const float* noise, const float* cache_source, int cache_len,
                     float* pcm, float* source_out, int mem);
+/* mia_hift_vocode for n utterances in one pass (an MI355X-side addition, like mia_flow_inference_batch: the reference vocodes its
+ * utterances one after another, CosyVoice2Model.swift:200-208).  mels: the utterances' [in_channels][T[u]] blocks back to back; noise
+ * (nullable): their [480 T[u]][nb_harmonics+1] blocks back to back; pcm: 480 T[u] samples per utterance back to back.  Every
+ * convolution runs once over the stacked sequences (a sequence's rows past its own end read as zero, the padding its single call
+ * sees); each utterance's waveform equals its own mia_hift_vocode call bit for bit.  1 <= n <= 64.  The cache_source hand-over of
+ * the streaming path stays with the single-utterance call.  Returns after the waveforms are in `pcm`. */
+int mia_hift_vocode_batch(mia_hift* h, const float* mels, const int32_t* T, int n, const float* noise, float* pcm, int mem);
 
 /* ---- CosyVoice2 flow (speech tokens -> 80-bin mel @ 50 Hz) ---------------------------------------- */
 /* FlowConfig (TTS/CosyVoice2/Config/CosyVoice2Config.swift:79-127).  Built for the shapes the reference engine uses: head dim 64 in

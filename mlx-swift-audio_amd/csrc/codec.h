@@ -29,6 +29,13 @@ struct ConvGemmArgs {
                                        // beyond it read as zero like rows past T_in (padded stacked sequences under a forward-looking window)
   int x_phase_step = 0;                // rows of X skipped per grid.z phase: stacked sequences of T_in rows each (taps never cross
                                        // a sequence; pair with w_phase_stride = 0, y_row_mul = 1, y_phase_step = rows per sequence)
+  // Stacked sequences under ANY row mapping (HiFT batches: plain, strided and transposed convolutions): grid.z = n_seq x phases,
+  // sequence u = z / phases reads X + u * x_seq_step rows (T_in = rows per sequence, seq_len[u] <= T_in of them valid, the rest read
+  // as zero like rows past T_in) and writes rows u * y_seq_step + row(m) of Y (R and R2 likewise); row(m) is tested against T_out
+  // per sequence.  n_seq = 1: everything above is unchanged.
+  int n_seq = 1;
+  int64_t x_seq_step = 0, y_seq_step = 0;
+  const int32_t* seq_len = nullptr;    // device [n_seq], optional
 };
 
 constexpr int MIA_MAX_LEVELS = 4;

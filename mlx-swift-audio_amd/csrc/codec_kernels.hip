@@ -57,10 +57,12 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
-  const int z = blockIdx.z;
+  int z = blockIdx.z, u = 0;
+  if (g.n_seq > 1) { const int pps = (int)gridDim.z / g.n_seq; u = z / pps; z -= u * pps; }     // grid.z = sequence x phase
   const float* __restrict__ W = g.W + (int64_t)z * g.w_phase_stride;
-  const float* __restrict__ X = g.X + (int64_t)z * g.x_phase_step * g.ldx;   // stacked sequences: phase z reads its own rows only
-  const int T_valid = g.phase_len ? min(g.T_in, g.phase_len[z]) : g.T_in;      // padded sequence: rows past its own length are zeros
+  const float* __restrict__ X = g.X + ((int64_t)z * g.x_phase_step + (int64_t)u * g.x_seq_step) * g.ldx;   // stacked sequences read their own rows only
+  const int T_valid = g.seq_len ? min(g.T_in, g.seq_len[u]) : g.phase_len ? min(g.T_in, g.phase_len[z]) : g.T_in;   // padded sequence: rows past its own length are zeros
+  const int64_t y_seq = (int64_t)u * g.y_seq_step;
   const int Ktot = g.taps * g.Cin;
   const int64_t ldw = g.ldw > 0 ? g.ldw : Ktot;
 
@@ -214,8 +216,9 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(ConvGemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wr * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= g.M) continue;
-        const int64_t yr = (int64_t)m * g.y_row_mul + g.y_row_off + (int64_t)z * g.y_phase_step;
+        int64_t yr = (int64_t)m * g.y_row_mul + g.y_row_off + (int64_t)z * g.y_phase_step;
         if (yr < 0 || yr >= g.T_out) continue;
+        yr += y_seq;
         float v = acc[i][j][r] + bias;
         if (g.gelu == 1) v = gelu_erf(v);
         else if (g.gelu == 2) v = v > 0.f ? v : (__expf(v) - 1.0f);
@@ -415,6 +418,7 @@ const char* codec_conv_gemm_check(const ConvGemmArgs& g) {
   if (g.Cin % 32) return "conv_gemm: Cin must be a multiple of 32";
   if (g.ldx % 4 || ((uintptr_t)g.X & 15) || ((uintptr_t)g.W & 15)) return "conv_gemm: X rows / W must be 16-byte aligned";
   if (g.noise && !g.R) return "conv_gemm: noise modulation needs the residual input";
+  if (g.n_seq < 1 || (g.n_seq > 1 && (g.x_seq_step < g.T_in || g.y_seq_step <= 0 || g.noise || g.x_phase_step))) return "conv_gemm: bad stacked-sequence arguments";
   if ((int64_t)g.M * g.x_row_mul + (int64_t)g.taps * g.dil > 0x7fffffffLL) return "conv_gemm: row index exceeds 31 bits";
   if (((int64_t)g.M * g.x_row_mul + (int64_t)g.taps * g.dil + g.pad + g.T_in) * g.ldx > 0x7fffffffLL) return "conv_gemm: row offset exceeds 31 bits";
   return nullptr;
@@ -428,6 +432,13 @@ static thread_local double t_alg_bytes = 0.0;
 double codec_alg_bytes(bool reset) { const double v = t_alg_bytes; if (reset) t_alg_bytes = 0.0; return v; }
 
 static void account_conv_gemm(const ConvGemmArgs& g, int phases) {
+  if (g.n_seq > 1) {                                                  // n_seq independent problems of the n_seq = 1 shape
+    ConvGemmArgs one = g; one.n_seq = 1;
+    const double before = t_alg_bytes;
+    account_conv_gemm(one, phases);
+    t_alg_bytes = before + (t_alg_bytes - before) * g.n_seq;
+    return;
+  }
   const bool stacked = g.x_phase_step != 0;                          // grid.z = stacked sequences (own X rows); else = stride phases of ONE input
   const double rows_in = std::min<double>((double)g.T_in, (double)g.M * g.x_row_mul + (double)g.taps * g.dil);
   double b = rows_in * g.Cin * 4.0 * (stacked ? phases : 1);
@@ -440,8 +451,9 @@ static void account_conv_gemm(const ConvGemmArgs& g, int phases) {
   t_alg_bytes += b;
 }
 
-int codec_conv_gemm_launch(const ConvGemmArgs& g, int phases, hipStream_t s) {
-  account_conv_gemm(g, phases);
+int codec_conv_gemm_launch(const ConvGemmArgs& g, int phases_per_seq, hipStream_t s) {
+  account_conv_gemm(g, phases_per_seq);
+  const int phases = phases_per_seq * (g.n_seq > 1 ? g.n_seq : 1);
   // 128-row tiles only when they still give every CU work; otherwise 64 x 64 tiles (4x the workgroups)
   const int64_t big_blocks = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * phases;
   if (big_blocks < 384) {

@@ -285,22 +285,34 @@ struct ConvOpt {
   int ldy = 0;   // 0 = N
 };
 
-int run_conv(mia_hift* h, const Conv& c, const float* X, int64_t T_in, float* Y, int64_t T_out, const ConvOpt& o = ConvOpt()) {
+// Stacked utterances (mia_hift_vocode_batch): U sequences side by side in every buffer, sequence u at row u * (rows per sequence) of
+// its buffer; len[u] = its valid rows in the convolution's INPUT (the rest of its rows read as zero, like the padding past a single
+// utterance's end).  U = 1 (every single-utterance entry point): the launches are exactly the unstacked ones.
+struct Seq { int U = 1; const int32_t* len = nullptr; };
+
+void seq_args(ConvGemmArgs& g, const Seq& q, int64_t x_rows, int64_t y_rows) {
+  if (q.U <= 1) return;
+  g.n_seq = q.U; g.x_seq_step = x_rows; g.y_seq_step = y_rows; g.seq_len = q.len;
+}
+
+int run_conv(mia_hift* h, const Conv& c, const float* X, int64_t T_in, float* Y, int64_t T_out, const ConvOpt& o = ConvOpt(), const Seq& q = Seq()) {
   ConvGemmArgs g;
   g.X = X; g.ldx = c.Cin; g.T_in = (int)T_in; g.W = c.w; g.bias = c.b; g.alpha = c.alpha; g.ralpha = c.ralpha; g.lrelu_slope = o.lrelu;
   g.Y = Y; g.ldy = o.ldy ? o.ldy : c.N; g.T_out = (int)T_out; g.R = o.R; g.R2 = o.R2; g.ldr = c.N; g.out_scale = o.scale;
   g.M = (int)T_out; g.N = c.N; g.Cin = c.Cin; g.taps = c.taps; g.dil = c.dil; g.pad = c.pad; g.x_row_mul = c.stride; g.gelu = o.act;
+  seq_args(g, q, T_in, T_out);
   if (const char* e = codec_conv_gemm_check(g)) return mia_fail(h->ctx, MIA_ERR_INVALID_ARGUMENT, "hift: %s", e);
   if (codec_conv_gemm_launch(g, 1, h->ctx->stream)) return mia_fail(h->ctx, MIA_ERR_DEVICE, "hift: conv launch failed");
   return MIA_OK;
 }
 
-// transposed conv: Y rows [row_shift, row_shift + T_out) of a buffer with T_out + row_shift rows
-int run_convt(mia_hift* h, const Conv& c, const float* X, int64_t T_in, float* Y, int64_t T_out, int row_shift, float lrelu) {
+// transposed conv: Y rows [row_shift, row_shift + T_out) of a buffer with T_out + row_shift rows (per sequence)
+int run_convt(mia_hift* h, const Conv& c, const float* X, int64_t T_in, float* Y, int64_t T_out, int row_shift, float lrelu, const Seq& q = Seq()) {
   ConvGemmArgs g;
   g.X = X; g.ldx = c.Cin; g.T_in = (int)T_in; g.W = c.w; g.w_phase_stride = (int64_t)c.N * c.taps * c.Cin; g.bias = c.b; g.lrelu_slope = lrelu;
   g.M = (int)T_in + c.taps - 1; g.N = c.N; g.Cin = c.Cin; g.taps = c.taps; g.dil = 1; g.pad = c.taps - 1;
   g.Y = Y + (int64_t)row_shift * c.N; g.ldy = c.N; g.T_out = (int)T_out; g.y_row_mul = c.stride; g.y_row_off = -c.pad; g.y_phase_step = 1;
+  seq_args(g, q, T_in, T_out + row_shift);
   if (const char* e = codec_conv_gemm_check(g)) return mia_fail(h->ctx, MIA_ERR_INVALID_ARGUMENT, "hift: %s", e);
   if (codec_conv_gemm_launch(g, c.stride, h->ctx->stream)) return mia_fail(h->ctx, MIA_ERR_DEVICE, "hift: convT launch failed");
   return MIA_OK;
@@ -308,49 +320,66 @@ int run_convt(mia_hift* h, const Conv& c, const float* X, int64_t T_in, float* Y
 
 // HiFiGANResBlock (HiFiGAN.swift:117-130).  x: input (left untouched), xt: scratch, res: running result; the last pair writes
 // out = scale * (conv2(..) + res) + R2 (scale 0 = plain) so that means and sums fold into the final epilogue.
-int run_resblock(mia_hift* h, const ResBlock& rb, const float* x, float* xt, float* res, float* out, int64_t T, float scale, const float* R2) {
+int run_resblock(mia_hift* h, const ResBlock& rb, const float* x, float* xt, float* res, float* out, int64_t T, float scale, const float* R2,
+                 const Seq& q = Seq()) {
   const int nd = h->cfg.n_dilations;
   for (int i = 0; i < nd; ++i) {
     const float* in = i == 0 ? x : res;
-    if (int rc = run_conv(h, rb.c1[i], in, T, xt, T)) return rc;
+    if (int rc = run_conv(h, rb.c1[i], in, T, xt, T, ConvOpt(), q)) return rc;
     ConvOpt o; o.R = in;
     float* dst = res;
     if (i == nd - 1) { dst = out; o.scale = scale; o.R2 = R2; }
-    if (int rc = run_conv(h, rb.c2[i], xt, T, dst, T, o)) return rc;
+    if (int rc = run_conv(h, rb.c2[i], xt, T, dst, T, o, q)) return rc;
   }
   return MIA_OK;
 }
 
+// p.T / L / F / rows: the LONGEST utterance of the call (every buffer holds U sequences of that many rows); Tu / Lu / Fu: each one's own
 struct Plan {
   int64_t T, L, F;
   int64_t rows[4]; int ch[4];
-  size_t big;   // floats per ping-pong buffer
+  size_t big;   // floats per ping-pong buffer and sequence
+  int U = 1;
+  std::vector<int64_t> Tu, Lu, Fu;
+  // device [U] valid-row tables of the stacked call (null at U = 1): mel frames, STFT frames, rows after upsample stage i
+  const int32_t* len_T = nullptr; const int32_t* len_F = nullptr; const int32_t* len_rows[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
-Plan make_plan(const mia_hift* h, int T) {
-  Plan p; p.T = T; p.L = (int64_t)T * h->up; p.F = p.L / 4 + 1;
-  int64_t r = T; size_t big = (size_t)T * h->cfg.base_channels;
-  for (int i = 0; i < h->cfg.n_ups; ++i) {
+int64_t rows_after(const mia_hift* h, int64_t T, int stage) {
+  int64_t r = T;
+  for (int i = 0; i <= stage; ++i) {
     const Conv& u = h->ups[i];
     r = (r - 1) * u.stride - 2 * u.pad + u.K;
     if (i == h->cfg.n_ups - 1) r += 1;
-    p.rows[i] = r; p.ch[i] = u.N;
-    big = std::max(big, (size_t)r * u.N);
+  }
+  return r;
+}
+
+Plan make_plan(const mia_hift* h, int T) {
+  Plan p; p.T = T; p.L = (int64_t)T * h->up; p.F = p.L / 4 + 1;
+  size_t big = (size_t)T * h->cfg.base_channels;
+  for (int i = 0; i < h->cfg.n_ups; ++i) {
+    const Conv& u = h->ups[i];
+    p.rows[i] = rows_after(h, T, i); p.ch[i] = u.N;
+    big = std::max(big, (size_t)p.rows[i] * u.N);
   }
   p.big = big + 64;
+  p.Tu = {p.T}; p.Lu = {p.L}; p.Fu = {p.F};
   return p;
 }
 
 struct Scratch {
   float *mel_raw, *melp, *fa, *fb, *f0, *P, *s, *noise, *cache, *stft, *post, *fr, *pcm, *big[4];
+  int32_t* lens = nullptr;      // stacked call: the plan's valid-row tables
 };
 
 int carve(mia_hift* h, const Plan& p, Scratch& sc) {
   const int C = h->cfg.in_channels, B = h->cfg.base_channels;
+  const size_t U = (size_t)p.U;
   auto al = [](size_t n) { return (n + 63) / 64 * 64; };
-  size_t sizes[] = {al((size_t)C * p.T), al((size_t)h->Cp_mel * p.T), al((size_t)B * p.T), al((size_t)B * p.T), al(p.T), al((size_t)p.T * h->H),
-                    al(p.L), al((size_t)p.L * h->H), al(p.L), al((size_t)p.F * 32), al((size_t)p.F * 18), al((size_t)p.F * 16), al(p.L),
-                    al(p.big), al(p.big), al(p.big), al(p.big)};
+  size_t sizes[] = {al(U * C * p.T), al(U * h->Cp_mel * p.T), al(U * B * p.T), al(U * B * p.T), al(U * p.T), al(U * p.T * h->H),
+                    al(U * p.L), al(U * p.L * h->H), al(p.L), al(U * p.F * 32), al(U * p.F * 18), al(U * p.F * 16), al(U * p.L),
+                    al(U * p.big), al(U * p.big), al(U * p.big), al(U * p.big), al(U * 8)};
   size_t tot = 0;
   for (size_t s : sizes) tot += s;
   if (tot > h->arena_floats) {
@@ -364,6 +393,7 @@ int carve(mia_hift* h, const Plan& p, Scratch& sc) {
   float** dst[] = {&sc.mel_raw, &sc.melp, &sc.fa, &sc.fb, &sc.f0, &sc.P, &sc.s, &sc.noise, &sc.cache, &sc.stft, &sc.post, &sc.fr, &sc.pcm,
                    &sc.big[0], &sc.big[1], &sc.big[2], &sc.big[3]};
   for (int i = 0; i < 17; ++i) { *dst[i] = q; q += sizes[i]; }
+  sc.lens = reinterpret_cast<int32_t*>(q);
   return MIA_OK;
 }
 
@@ -373,70 +403,98 @@ int download(mia_hift* h, float* dst, const float* src, size_t n) {
   return MIA_OK;
 }
 
+// mel of sequence u: [C][Tu] at mel + C * (sum of the T before it); packed to [u][p.T][Cp] (single call: u = 0, offset 0)
 int upload_mel(mia_hift* h, const Plan& p, Scratch& sc, const float* mel, bool dev) {
   hipStream_t s = h->ctx->stream;
   const int C = h->cfg.in_channels;
+  int64_t tot = 0;
+  for (int64_t t : p.Tu) tot += t;
   if (dev) sc.mel_raw = const_cast<float*>(mel);
-  else MIA_HIP(h->ctx, hipMemcpyAsync(sc.mel_raw, mel, (size_t)C * p.T * 4, hipMemcpyHostToDevice, s));
-  dim3 grid((unsigned)((p.T + 31) / 32), (unsigned)(h->Cp_mel / 32));
-  hipLaunchKernelGGL(hift_pack_mel, grid, dim3(256), 0, s, sc.mel_raw, sc.melp, C, h->Cp_mel, (int)p.T);
+  else MIA_HIP(h->ctx, hipMemcpyAsync(sc.mel_raw, mel, (size_t)C * tot * 4, hipMemcpyHostToDevice, s));
+  if (p.U > 1) MIA_HIP(h->ctx, hipMemsetAsync(sc.melp, 0, (size_t)p.U * p.T * h->Cp_mel * 4, s));      // rows past an utterance's end
+  int64_t off = 0;
+  for (int u = 0; u < p.U; ++u) {
+    dim3 grid((unsigned)((p.Tu[u] + 31) / 32), (unsigned)(h->Cp_mel / 32));
+    hipLaunchKernelGGL(hift_pack_mel, grid, dim3(256), 0, s, sc.mel_raw + (int64_t)C * off, sc.melp + (int64_t)u * p.T * h->Cp_mel, C, h->Cp_mel, (int)p.Tu[u]);
+    off += p.Tu[u];
+  }
   return MIA_OK;
 }
 
 int dev_f0(mia_hift* h, const Plan& p, const Scratch& sc) {
   ConvOpt elu; elu.act = 2;
+  Seq q; q.U = p.U; q.len = p.len_T;
   const float* x = sc.melp; float* a = sc.fa; float* b = sc.fb;
   for (int i = 0; i < 5; ++i) {
-    if (int rc = run_conv(h, h->f0c[i], x, p.T, a, p.T, elu)) return rc;
+    if (int rc = run_conv(h, h->f0c[i], x, p.T, a, p.T, elu, q)) return rc;
     x = a; std::swap(a, b);
   }
   ConvOpt ab; ab.act = 3; ab.ldy = 1;
-  return run_conv(h, h->cls, x, p.T, sc.f0, p.T, ab);
+  return run_conv(h, h->cls, x, p.T, sc.f0, p.T, ab, q);
 }
 
+// noise of sequence u: [Lu][H] at noise + H * (sum of the L before it); source [u][p.L]
 int dev_source(mia_hift* h, const Plan& p, const Scratch& sc, bool have_noise, int cache_len) {
   hipStream_t s = h->ctx->stream;
   const mia_hift_config& g = h->cfg;
-  hipLaunchKernelGGL(hift_phase_scan, dim3(1), dim3(256), 0, s, sc.f0, sc.P, (int)p.T, h->H, (float)g.sampling_rate, (float)h->up);
-  const float ratio = (float)p.T / (float)p.L;
-  const float clip_hi = (float)p.T - 1.001f;
-  hipLaunchKernelGGL(hift_source_kernel, dim3((unsigned)((p.L + 255) / 256)), dim3(256), 0, s, sc.f0, sc.P, have_noise ? sc.noise : nullptr,
-                     h->lw, h->lb, sc.cache, cache_len, sc.s, (int)p.T, h->up, h->H, ratio, clip_hi, g.nsf_alpha, g.nsf_sigma,
-                     g.voiced_threshold);
+  int64_t noff = 0;
+  for (int u = 0; u < p.U; ++u) {
+    const int64_t T = p.Tu[u], L = p.Lu[u];
+    const float* f0 = sc.f0 + (int64_t)u * p.T;
+    float* P = sc.P + (int64_t)u * p.T * h->H;
+    hipLaunchKernelGGL(hift_phase_scan, dim3(1), dim3(256), 0, s, f0, P, (int)T, h->H, (float)g.sampling_rate, (float)h->up);
+    const float ratio = (float)T / (float)L;
+    const float clip_hi = (float)T - 1.001f;
+    hipLaunchKernelGGL(hift_source_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, f0, P, have_noise ? sc.noise + noff * h->H : nullptr,
+                       h->lw, h->lb, sc.cache, cache_len, sc.s + (int64_t)u * p.L, (int)T, h->up, h->H, ratio, clip_hi, g.nsf_alpha, g.nsf_sigma,
+                       g.voiced_threshold);
+    noff += L;
+  }
   return hipGetLastError() == hipSuccess ? MIA_OK : mia_fail(h->ctx, MIA_ERR_DEVICE, "hift: source launch failed");
 }
 
 int dev_decode(mia_hift* h, const Plan& p, const Scratch& sc) {
   hipStream_t s = h->ctx->stream;
   const mia_hift_config& g = h->cfg;
-  hipLaunchKernelGGL(hift_stft, dim3((unsigned)((p.F + 255) / 256)), dim3(256), 0, s, sc.s, sc.stft, p.L, p.F);
+  const int U = p.U;
+  if (U > 1) MIA_HIP(h->ctx, hipMemsetAsync(sc.stft, 0, (size_t)U * p.F * 32 * 4, s));                  // frames past an utterance's end
+  for (int u = 0; u < U; ++u)
+    hipLaunchKernelGGL(hift_stft, dim3((unsigned)((p.Fu[u] + 255) / 256)), dim3(256), 0, s, sc.s + (int64_t)u * p.L, sc.stft + (int64_t)u * p.F * 32, p.Lu[u], p.Fu[u]);
   float* A = sc.big[0]; float* B = sc.big[1]; float* C = sc.big[2]; float* D = sc.big[3];
-  if (int rc = run_conv(h, h->pre, sc.melp, p.T, A, p.T)) return rc;
+  Seq qT; qT.U = U; qT.len = p.len_T;
+  Seq qF; qF.U = U; qF.len = p.len_F;
+  if (int rc = run_conv(h, h->pre, sc.melp, p.T, A, p.T, ConvOpt(), qT)) return rc;
   int64_t rows = p.T;
+  Seq qin = qT;
   for (int i = 0; i < g.n_ups; ++i) {
     const bool last = i == g.n_ups - 1;
     const int64_t r_out = p.rows[i]; const int Ci = p.ch[i];
+    Seq qr; qr.U = U; qr.len = p.len_rows[i];
     // leaky-ReLU -> ConvTransposed1d (-> prepend the reflected sample: new[0] = old[1] = new[2])
-    if (int rc = run_convt(h, h->ups[i], A, rows, D, last ? r_out - 1 : r_out, last ? 1 : 0, g.lrelu_slope)) return rc;
-    if (last) MIA_HIP(h->ctx, hipMemcpyAsync(D, D + 2 * (int64_t)Ci, (size_t)Ci * 4, hipMemcpyDeviceToDevice, s));
+    if (int rc = run_convt(h, h->ups[i], A, rows, D, last ? r_out - 1 : r_out, last ? 1 : 0, g.lrelu_slope, qin)) return rc;
+    if (last) MIA_HIP(h->ctx, hipMemcpy2DAsync(D, (size_t)r_out * Ci * 4, D + 2 * (int64_t)Ci, (size_t)r_out * Ci * 4, (size_t)Ci * 4, (size_t)U, hipMemcpyDeviceToDevice, s));
     std::swap(A, D);
     rows = r_out;
     // source fusion: h += source_resblock(source_down(stft))
     const Conv& sd = h->sdown[i];
     const int64_t sd_rows = (p.F + 2 * sd.pad - sd.taps) / sd.stride + 1;
     if (sd_rows != rows) return mia_fail(h->ctx, MIA_ERR_INVALID_ARGUMENT, "hift: source_downs.%d yields %lld rows, the upsampled stream has %lld", i, (long long)sd_rows, (long long)rows);
-    if (int rc = run_conv(h, sd, sc.stft, p.F, C, rows)) return rc;
-    if (int rc = run_resblock(h, h->srb[i], C, B, C, A, rows, 1.0f, A)) return rc;
+    if (int rc = run_conv(h, sd, sc.stft, p.F, C, rows, ConvOpt(), qF)) return rc;
+    if (int rc = run_resblock(h, h->srb[i], C, B, C, A, rows, 1.0f, A, qr)) return rc;
     // mean of the residual blocks
     const float inv = 1.0f / (float)g.n_res_kernels;
     for (int k = 0; k < g.n_res_kernels; ++k)
-      if (int rc = run_resblock(h, h->rb[i][k], A, B, C, D, rows, inv, k == 0 ? nullptr : D)) return rc;
+      if (int rc = run_resblock(h, h->rb[i][k], A, B, C, D, rows, inv, k == 0 ? nullptr : D, qr)) return rc;
     std::swap(A, D);
+    qin = qr;
   }
   ConvOpt o; o.lrelu = 0.01f;   // default negative_slope before conv_post (CosyHiFTGenerator.swift:445-446)
-  if (int rc = run_conv(h, h->post, A, rows, sc.post, rows, o)) return rc;
-  hipLaunchKernelGGL(hift_istft_frames, dim3((unsigned)((p.F + 255) / 256)), dim3(256), 0, s, sc.post, sc.fr, p.F);
-  hipLaunchKernelGGL(hift_overlap_add, dim3((unsigned)((p.L + 255) / 256)), dim3(256), 0, s, sc.fr, sc.pcm, p.F, p.L, g.audio_limit);
+  if (int rc = run_conv(h, h->post, A, rows, sc.post, rows, o, qin)) return rc;
+  for (int u = 0; u < U; ++u) {
+    const int64_t F = p.Fu[u], L = p.Lu[u];
+    hipLaunchKernelGGL(hift_istft_frames, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, s, sc.post + (int64_t)u * rows * 18, sc.fr + (int64_t)u * p.F * 16, F);
+    hipLaunchKernelGGL(hift_overlap_add, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, sc.fr + (int64_t)u * p.F * 16, sc.pcm + (int64_t)u * p.L, F, L, g.audio_limit);
+  }
   return hipGetLastError() == hipSuccess ? MIA_OK : mia_fail(h->ctx, MIA_ERR_DEVICE, "hift: istft launch failed");
 }
 
@@ -582,6 +640,52 @@ int mia_hift_vocode(mia_hift* h, const float* mel, int T, const float* noise, co
   if (dev) return MIA_OK;
   if (source_out) MIA_HIP(h->ctx, hipMemcpyAsync(source_out, sc.s, (size_t)p.L * 4, hipMemcpyDeviceToHost, s));
   return download(h, pcm, sc.pcm, (size_t)p.L);
+}
+
+// U utterances in one pass: every convolution of the f0 predictor and of the decoder runs once over the stacked sequences (grid.z =
+// sequence x phase of the tap GEMM; a sequence's rows past its own end read as zero, exactly the padding a single call sees), the
+// per-sample stages (phase scan, sine source, STFT, iSTFT, overlap-add) run per utterance.  mels: [C][T_u] blocks back to back; noise
+// (optional): [L_u][H] blocks back to back, L_u = T_u * upsample_factor; pcm: L_u samples per utterance back to back.  Every utterance
+// equals its own mia_hift_vocode call bit for bit (tests/test_hift_gpu.py).  The cache_source hand-over of the streaming path stays
+// with the single-utterance call.
+int mia_hift_vocode_batch(mia_hift* h, const float* mels, const int32_t* T, int n, const float* noise, float* pcm, int mem) {
+  if (!h) return MIA_ERR_INVALID_ARGUMENT;
+  MIA_CHECK_ARG(h->ctx, mels && T && pcm && n >= 1 && n <= 64 && (mem == MIA_MEM_HOST || mem == MIA_MEM_DEVICE), "hift_vocode_batch: bad argument (1 <= n <= 64)");
+  int Tm = 0;
+  for (int u = 0; u < n; ++u) { if (int rc = check_T(h, T[u])) return rc; Tm = std::max(Tm, T[u]); }
+  MIA_HIP(h->ctx, hipSetDevice(h->ctx->device));
+  hipStream_t s = h->ctx->stream;
+  Plan p = make_plan(h, Tm); Scratch sc;
+  p.U = n; p.Tu.clear(); p.Lu.clear(); p.Fu.clear();
+  int64_t Ltot = 0;
+  for (int u = 0; u < n; ++u) { const int64_t L = (int64_t)T[u] * h->up; p.Tu.push_back(T[u]); p.Lu.push_back(L); p.Fu.push_back(L / 4 + 1); Ltot += L; }
+  if (int rc = carve(h, p, sc)) return rc;
+  const bool dev = mem == MIA_MEM_DEVICE;
+  std::vector<int32_t> lens((size_t)(2 + h->cfg.n_ups) * n);
+  for (int u = 0; u < n; ++u) {
+    lens[u] = T[u]; lens[(size_t)n + u] = (int32_t)p.Fu[u];
+    for (int i = 0; i < h->cfg.n_ups; ++i) lens[(size_t)(2 + i) * n + u] = (int32_t)rows_after(h, T[u], i);
+  }
+  if (n > 1) {
+    MIA_HIP(h->ctx, hipMemcpyAsync(sc.lens, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, s));
+    p.len_T = sc.lens; p.len_F = sc.lens + n;
+    for (int i = 0; i < h->cfg.n_ups; ++i) p.len_rows[i] = sc.lens + (size_t)(2 + i) * n;
+  }
+  if (int rc = upload_mel(h, p, sc, mels, dev)) return rc;
+  if (noise) {
+    if (dev) sc.noise = const_cast<float*>(noise);
+    else MIA_HIP(h->ctx, hipMemcpyAsync(sc.noise, noise, (size_t)Ltot * h->H * 4, hipMemcpyHostToDevice, s));
+  }
+  if (int rc = dev_f0(h, p, sc)) return rc;
+  if (int rc = dev_source(h, p, sc, noise != nullptr, 0)) return rc;
+  if (int rc = dev_decode(h, p, sc)) return rc;
+  int64_t off = 0;
+  for (int u = 0; u < n; ++u) {
+    MIA_HIP(h->ctx, hipMemcpyAsync(pcm + off, sc.pcm + (int64_t)u * p.L, (size_t)p.Lu[u] * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    off += p.Lu[u];
+  }
+  MIA_HIP(h->ctx, hipStreamSynchronize(s));       // (also keeps `lens` alive until its upload has been read)
+  return MIA_OK;
 }
 
 }  // extern "C"

@@ -38,6 +38,8 @@ def _declare(lib):
     lib.mia_hift_decode.argtypes = [vp, vp, i32, vp, vp, i32]
     lib.mia_hift_vocode.restype = i32
     lib.mia_hift_vocode.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32]
+    lib.mia_hift_vocode_batch.restype = i32
+    lib.mia_hift_vocode_batch.argtypes = [vp, vp, vp, i32, vp, vp, i32]
     lib._hift_declared = True
 
 
@@ -135,3 +137,21 @@ class HiFTGenerator:
         return pcm, src
 
     inference = __call__
+
+    def vocode_batch(self, mels, noises=None):
+        """mia_hift_vocode_batch: one pass over several utterances (mels: list of [80, T_u]; noises: matching list or None) ->
+        list of waveforms [480 T_u], each bit-identical to self(mel_u, noise=noise_u)[0]."""
+        ms = [self._mel(m) for m in mels]
+        T = np.asarray([m.shape[1] for m in ms], np.int32)
+        flat = np.concatenate([m.reshape(-1) for m in ms]).astype(np.float32)
+        nz = None
+        if noises is not None:
+            nz = np.concatenate([self._noise(n, int(t)).reshape(-1) for n, t in zip(noises, T)]).astype(np.float32)
+        pcm = np.empty(int(T.sum()) * self.up, np.float32)
+        self.ctx.check(self.ctx.lib.mia_hift_vocode_batch(self.h, flat.ctypes.data, T.ctypes.data, len(ms), nz.ctypes.data if nz is not None else None,
+                                                          pcm.ctypes.data, _lib.MEM_HOST))
+        out, off = [], 0
+        for t in T:
+            out.append(pcm[off:off + int(t) * self.up].copy())
+            off += int(t) * self.up
+        return out

@@ -105,7 +105,40 @@ def test_full_size_config(env):
     assert a.shape == (T * 480,) and np.isfinite(a).all() and np.abs(a).max() <= 0.99 + 1e-7
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(sa, sb)
+    # production configuration, stacked: three utterances of different lengths in one pass = their single calls, bit for bit
+    _check_batch(gen, [250, 97, 400], 31)
     gen.close()
+
+
+def _check_batch(gen, Ts, seed, with_noise=True):
+    rng = np.random.default_rng(seed)
+    mels = [_mel(T, seed + 7 * i) for i, T in enumerate(Ts)]
+    noises = [rng.standard_normal((T * gen.up, gen.cfg.nb_harmonics + 1)).astype(np.float32) for T in Ts] if with_noise else None
+    got = gen.vocode_batch(mels, noises)
+    assert len(got) == len(Ts)
+    for u, T in enumerate(Ts):
+        want, _ = gen(mels[u], noise=noises[u] if with_noise else None)
+        assert got[u].shape == (T * gen.up,)
+        assert np.array_equal(got[u], want), (u, T, np.abs(got[u] - want).max())
+
+
+def test_vocode_batch_equals_single_calls(env):
+    """mia_hift_vocode_batch: utterances of different lengths stacked into one pass (every convolution once over grid.z = sequence x
+    phase, rows past a sequence's end read as zero) give, utterance by utterance, the bits of their own single calls -- shortest and
+    longest first, a length-2 utterance next to long ones, with and without the additive noise."""
+    ctx, cfg, w, gen = env
+    _check_batch(gen, [40, 17, 40, 2, 63], 11)
+    _check_batch(gen, [5, 90], 12, with_noise=False)
+    _check_batch(gen, [33], 13)                          # n = 1 goes through the same entry point
+    # and against the oracle directly
+    from oracle import hift as OH
+    rng = np.random.default_rng(14)
+    mels = [_mel(21, 1), _mel(48, 2)]
+    noises = [rng.standard_normal((T * 480, 9)).astype(np.float32) for T in (21, 48)]
+    got = gen.vocode_batch(mels, noises)
+    for u in range(2):
+        src = gen(mels[u], noise=noises[u])[1]            # (f0's last-ulp error is amplified in the phase track: pin the source)
+        np.testing.assert_allclose(got[u], OH.decode(w, cfg, mels[u], src), atol=3e-4, rtol=1e-3)
 
 
 def test_errors(env):
