@@ -47,7 +47,7 @@ int dec_launch_reduce_ln(mia_whisper* w, int S, const float* bias, const LNW& ln
 // Whisper step: a.A in activation fragment order, a.W in weight fragment order (LinearW::wf)
 int dec_launch_skinny(mia_whisper* w, const SkinnyArgs& a, int mode, hipStream_t s);
 // c1[n] = sum_k W[n][k] gamma[k], c2[n] = sum_k W[n][k] beta[k] for a row-major 16-bit [N][K] matrix (fp32 sums in k order)
-int dec_launch_lnfold(const void* w16, int N, int K, const float* gamma, const float* beta, float* c1, float* c2, int dtype, hipStream_t s);
+int dec_launch_lnfold(const void* w16, int N, int K, const float* gamma, const float* beta, float* c1, float* c2, int dtype, hipStream_t s, const float* bias = nullptr);
 // row-major [N][K] 16-bit -> weight fragment order (dst holds ceil(N/16)*16*K elements; rows past N are zero)
 int dec_launch_repack_wfrag(const void* src, void* dst, int N, int K, hipStream_t s);
 // model-independent form (dtype = MIA_BF16 | MIA_F16); SK_SWIGLU: W rows interleaved gate/up, out[m][n/2] = silu(g)*u (16-bit)

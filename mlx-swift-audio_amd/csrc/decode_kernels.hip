@@ -586,20 +586,21 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
 // c1[n] = sum_k W[n][k] gamma[k], c2[n] = sum_k W[n][k] beta[k]: one wave per row of a row-major 16-bit matrix (load time, once per Linear)
 template <typename T>
 __global__ __launch_bounds__(256) void dec_lnfold(const uint16_t* __restrict__ w, int N, int K, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, float* __restrict__ c1, float* __restrict__ c2) {
+                                                  const float* __restrict__ beta, float* __restrict__ c1, float* __restrict__ c2,
+                                                  const float* __restrict__ bias) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= N) return;
   const uint16_t* wr = w + (int64_t)row * K;
   float s1 = 0.f, s2 = 0.f;
   for (int k = lane; k < K; k += 64) { const float v = T::to_f32(wr[k]); s1 = fmaf(v, gamma[k], s1); s2 = fmaf(v, beta[k], s2); }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
-  if (lane == 0) { c1[row] = s1; c2[row] = s2; }
+  if (lane == 0) { c1[row] = s1; c2[row] = s2 + (bias ? bias[row] : 0.f); }       // bias: the encoder's form, c2 + the Linear's own bias
 }
 
-int dec_launch_lnfold(const void* w16, int N, int K, const float* gamma, const float* beta, float* c1, float* c2, int dtype, hipStream_t s) {
+int dec_launch_lnfold(const void* w16, int N, int K, const float* gamma, const float* beta, float* c1, float* c2, int dtype, hipStream_t s, const float* bias) {
   if (!w16 || !gamma || !beta || !c1 || !c2 || N <= 0 || K <= 0) return -1;
-  if (dtype == MIA_F16) hipLaunchKernelGGL(dec_lnfold<F16>, dim3((N + 3) / 4), dim3(256), 0, s, (const uint16_t*)w16, N, K, gamma, beta, c1, c2);
-  else hipLaunchKernelGGL(dec_lnfold<BF16>, dim3((N + 3) / 4), dim3(256), 0, s, (const uint16_t*)w16, N, K, gamma, beta, c1, c2);
+  if (dtype == MIA_F16) hipLaunchKernelGGL(dec_lnfold<F16>, dim3((N + 3) / 4), dim3(256), 0, s, (const uint16_t*)w16, N, K, gamma, beta, c1, c2, bias);
+  else hipLaunchKernelGGL(dec_lnfold<BF16>, dim3((N + 3) / 4), dim3(256), 0, s, (const uint16_t*)w16, N, K, gamma, beta, c1, c2, bias);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -467,6 +467,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
   const int nk = g.K / BK;
   const int n_items = 4 * nk;
   char* const lds_wave = lds + (16 * wave) * 128;
+  // LayerNorm hand-over (gemm.h): the tile's per-row (mean, rstd) and per-column c1 (consumer) or gamma (producer) go to 4 KB of LDS
+  // behind the two K-tile buffers by LDS-DMA, issued BEFORE the first stage so that they are the oldest operations of every counted
+  // wait: fetched at the head of the epilogue they were a bare memory round trip per tile (1 workgroup per CU: nothing hides it;
+  // measured + 30 us on the MLP's first Linear).
+  char* const lds_ln = lds + 2 * KBUF_BYTES;            // [256 rows][2] stats | [256] c1 or gamma
+  if (EPI == MIA_EPI_STD && (g.ln_stat || g.ln_gamma)) {
+    if (g.ln_stat) {
+      int m = m0 + 32 * wave + (lane >> 1); m = m < g.M ? m : g.M - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.ln_stat + 2 * (int64_t)m + (lane & 1)),
+                                       (__attribute__((address_space(3))) void*)(lds_ln + wave * 256), 4, 0, 0);
+    }
+    if (wave < 4) {
+      const float* vsrc = g.ln_stat ? g.ln_c1 : g.ln_gamma;
+      int n = n0 + 64 * wave + lane; n = n < g.N ? n : g.N - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + n),
+                                       (__attribute__((address_space(3))) void*)(lds_ln + 2048 + wave * 256), 4, 0, 0);
+    }
+  }
   // item j = 4*t + {0: AX, 1: B0, 2: B1, 3: AY} of K-tile t
   // (`guard` = false in the steady part of the K loop, where every staged item exists: the range checks and the run-time choice of
   // the vmcnt immediate cost 31 scalar branches per pair of K-tiles, in a loop whose 128 MFMAs are otherwise back to back)
@@ -647,9 +665,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
                         (EPI == MIA_EPI_STD || n0 + BN2 <= 2 * g.H * 64);
     if (rows16) {
       char* reg = lds + wave * 16384;
+      // LayerNorm hand-over (gemm.h): per-row (mean, rstd) of this lane's 8 rows and c1 of its 16 columns, loaded before the staging
+      float st_m[8], st_r[8];
+      f32x4 c1v[4];
+      const bool ln = EPI == MIA_EPI_STD && g.ln_stat != nullptr;
+      if (ln) {            // (from LDS: staged at kernel start)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          const float2 mr = *reinterpret_cast<const float2*>(lds_ln + (wr * 128 + mt * 16 + e_m) * 8);
+          st_m[mt] = -mr.x; st_r[mt] = mr.y;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) c1v[nt] = *reinterpret_cast<const f32x4*>(lds_ln + 2048 + (wc * 64 + nt * 16 + e_n) * 4);
+      }
       // (the activation switch is taken ONCE per tile: tested per value it compiled into a branch around every one of the 128 GELUs)
-      auto stage16 = [&](auto gelu_tag) {
+      auto stage16 = [&](auto gelu_tag, auto ln_tag) {
         constexpr bool GELU = decltype(gelu_tag)::value;
+        constexpr bool LN = decltype(ln_tag)::value;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
           const int row = mt * 16 + e_m;
@@ -657,13 +689,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
           for (int nt = 0; nt < 4; ++nt) {
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = acc[mt][nt][j] + bias4[nt][j]; if (GELU) v[j] = gelu_erf(v[j]); }
+            for (int j = 0; j < 4; ++j) {
+              v[j] = LN ? fmaf(st_r[mt], fmaf(st_m[mt], c1v[nt][j], acc[mt][nt][j]), bias4[nt][j]) : acc[mt][nt][j] + bias4[nt][j];
+              if (GELU) v[j] = gelu_erf(v[j]);
+            }
             const int c16 = nt * 2 + (lane >> 5), half = (lane >> 4) & 1;
             *reinterpret_cast<u32x2*>(reg + row * 128 + ((c16 ^ (row & 7)) << 4) + half * 8) = (u32x2){pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
           }
         }
       };
-      if (g.act == MIA_ACT_GELU) stage16(std::true_type{}); else stage16(std::false_type{});
+      if (ln) { if (g.act == MIA_ACT_GELU) stage16(std::true_type{}, std::true_type{}); else stage16(std::false_type{}, std::true_type{}); }
+      else { if (g.act == MIA_ACT_GELU) stage16(std::true_type{}, std::false_type{}); else stage16(std::false_type{}, std::false_type{}); }
       uint16_t* cb = reinterpret_cast<uint16_t*>(g.C) + (EPI == MIA_EPI_STD ? (int64_t)bz * g.strideC : 0);
       const int c16 = lane & 7;
       const int n = n0 + wc * 64 + c16 * 8;
@@ -690,6 +726,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
       const int c16 = lane & 15;
       const int n = n0 + wc * 64 + c16 * 4;
       const bool gelu32 = g.act == MIA_ACT_GELU;
+      // LayerNorm hand-over (gemm.h): gamma of this lane's 4 columns; the row's 64 columns of this wave sit in the 16 lanes of a DPP row
+      const bool ln_out = g.ln_gamma != nullptr;
+      f32x4 gm = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ln_out) gm = *reinterpret_cast<const f32x4*>(lds_ln + 2048 + (wc * 64 + c16 * 4) * 4);      // (staged at kernel start)
+      const int ln_slices = g.N >> 6, ln_slice = (n0 + wc * 64) >> 6;
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh) {
         // the half's 16 residual vectors first: unconditional loads (row / column clamped into the tensor, unused lanes discard them),
@@ -731,6 +772,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_8ph(GemmArgs g) {
             for (int j = 0; j < 4; ++j) v[j] += rv[i][j];
           }
           if (m < g.M && n < g.N) *reinterpret_cast<f32x4*>(cb + (int64_t)m * g.ldc + n) = v;
+          if (ln_out) {
+            float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+            float s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+            s1 += dpp_f32<0xB1>(s1); s2 += dpp_f32<0xB1>(s2);
+            s1 += dpp_f32<0x4E>(s1); s2 += dpp_f32<0x4E>(s2);
+            s1 += dpp_f32<0x141>(s1); s2 += dpp_f32<0x141>(s2);
+            s1 += dpp_f32<0x140>(s1); s2 += dpp_f32<0x140>(s2);
+            if (m < g.M && n < g.N) {
+              if (c16 == 0) *reinterpret_cast<float2*>(g.ln_part + ((int64_t)m * ln_slices + ln_slice) * 2) = make_float2(s1, s2);
+              *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(g.ln_out) + (int64_t)m * g.ln_ld + n) =
+                  (u32x2){pack2<T>(v[0] * gm[0], v[1] * gm[1]), pack2<T>(v[2] * gm[2], v[3] * gm[3])};
+            }
+          }
         }
       }
       return;
@@ -753,11 +807,11 @@ template <typename T>
 int launch_8ph(const GemmArgs& g, hipStream_t s) {
   const int tiles = ((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
   dim3 grid(tiles, 1, g.batch > 0 ? g.batch : 1), block(512);
-  const size_t lds_bytes = 2 * KBUF_BYTES;
+  const size_t lds_bytes = 2 * KBUF_BYTES + 4096;      // two K-tile buffers + the LayerNorm hand-over vectors
 #define L8(F32, E)                                                                                                \
   do {                                                                                                            \
     static std::once_flag once;                                                                                   \
-    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_8ph<T, F32, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF_BYTES); }); \
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_8ph<T, F32, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KBUF_BYTES + 4096); }); \
     hipLaunchKernelGGL((gemm_nt_kernel_8ph<T, F32, E>), grid, block, lds_bytes, s, g);                             \
   } while (0)
   if (g.epi == MIA_EPI_STD) { if (g.out_f32) L8(true, MIA_EPI_STD); else L8(false, MIA_EPI_STD); }
@@ -810,13 +864,39 @@ int launch_t(const GemmArgs& g, hipStream_t s) {
   if (g.variant == 4) return ok8 ? launch_8ph<T>(g, s) : launch_256<T>(g, s);
   // auto: the 256^2 tile needs enough tiles to fill 256 CUs; small problems keep the 128^2 tile
   const long tiles256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.batch > 0 ? g.batch : 1);
+  if (ok8 && (g.ln_gamma || g.ln_stat)) return launch_8ph<T>(g, s);      // (gemm_uses_8ph: hand-over pairs at every size)
   if (tiles256 < 256) return launch_ts<T, 1>(g, s);
   return ok8 ? launch_8ph<T>(g, s) : launch_256<T>(g, s);
 }
 
 }  // namespace
 
+static bool gemm_uses_8ph(const GemmArgs& g) {
+  const bool ok8 = g.K >= 2 * BK && (int64_t)g.M * g.lda * 2 < (1ll << 32) && (int64_t)g.N * g.K * 2 < (1ll << 32);
+  if (!ok8) return false;
+  if (g.variant == 4) return true;
+  if (g.variant != 3) return false;
+  // a LayerNorm hand-over pair runs on this kernel at EVERY size: its arithmetic (16-bit x * gamma operand, statistics applied in the
+  // epilogue) differs from the LayerNorm kernel's in the last bit, and a clip's features must not depend on the batch it sits in
+  if (g.ln_gamma || g.ln_stat) return true;
+  return (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.batch > 0 ? g.batch : 1) >= 256;
+}
+
+bool mia_gemm_ln_ok(const GemmArgs& g) {
+  if (!gemm_uses_8ph(g) || g.epi != MIA_EPI_STD || g.batch > 1) return false;
+  if (g.ln_gamma) {          // producer: the fp32 row form of the epilogue (rows32)
+    if (!g.out_f32 || (g.N & 63) || (g.ldc & 3) || ((uintptr_t)g.C & 15) || (g.strideC & 3) || !g.ln_out || !g.ln_part || (g.ln_ld & 3) ||
+        ((uintptr_t)g.ln_out & 7) || ((uintptr_t)g.ln_gamma & 15)) return false;
+    if (g.R && ((g.ldr & 3) || ((uintptr_t)g.R & 15) || (g.strideR & 3))) return false;
+  }
+  if (g.ln_stat) {           // consumer: the 16-bit row form (rows16)
+    if (g.out_f32 || g.R || (g.N & 7) || (g.ldc & 7) || ((uintptr_t)g.C & 15) || (g.strideC & 7) || !g.ln_c1 || ((uintptr_t)g.ln_c1 & 15) || !g.bias) return false;
+  }
+  return true;
+}
+
 const char* mia_gemm_check(const GemmArgs& g) {
+  if ((g.ln_gamma || g.ln_stat) && !mia_gemm_ln_ok(g)) return "gemm: the LayerNorm hand-over fields need the 8-phase kernel's row epilogues (mia_gemm_ln_ok)";
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return "gemm: M, N, K must be > 0";
   if (g.K % BK != 0) return "gemm: K must be a multiple of 64";
   if (g.lda % 8 != 0) return "gemm: lda must be a multiple of 8 elements (16-byte rows)";

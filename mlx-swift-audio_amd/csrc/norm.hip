@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include "mia_device.h"
 #include "ops.h"
+#include "gemm.h"
 
 namespace {
 
@@ -82,6 +83,28 @@ void launch_nv(const float* x, int64_t ldx, const float* gamma, const float* bet
 }
 
 }  // namespace
+
+namespace {
+// (sum x, sum x^2) per row and 64-column slice (the residual GEMM's epilogue, gemm.h) -> (mean, rstd) per row; the slices are added in
+// double, so the only rounding is that of the 64-element fp32 partial sums
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int n_slices, float inv_d, float eps, float* __restrict__ stat, int M) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= M) return;
+  const float2* p = reinterpret_cast<const float2*>(part) + (int64_t)row * n_slices;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = 0; t < n_slices; ++t) { const float2 v = p[t]; s1 += (double)v.x; s2 += (double)v.y; }
+  const double mean = s1 * (double)inv_d;
+  double var = s2 * (double)inv_d - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  *reinterpret_cast<float2*>(stat + 2 * (int64_t)row) = make_float2((float)mean, rsqrtf((float)var + eps));
+}
+}  // namespace
+
+int mia_ln_finalize_launch(const float* part, int n_slices, int D, float eps, float* stat, int M, hipStream_t s) {
+  if (!part || !stat || n_slices <= 0 || D <= 0 || M <= 0) return -1;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part, n_slices, 1.0f / (float)D, eps, stat, M);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 const char* mia_norm_check(int M, int D, int64_t ldx, int64_t ldy) {
   if (M <= 0 || D <= 0) return "norm: M and D must be > 0";

@@ -62,6 +62,8 @@ int whisper_reserve(mia_whisper* w, int B) {
   A(att, M * D * 2, false);
   A(g, M * 4 * D * 2, false);
   A(feat, M * D * 2, false);
+  A(enc_part, M * (D / 64 + 1) * 2 * 4, false);
+  A(enc_stat, M * 2 * 4, false);
   A(cross_k, L * M * D * 2, false);
   A(cross_v, L * M * D * 2, false);
   // decoder
@@ -109,7 +111,7 @@ int whisper_reserve(mia_whisper* w, int B) {
   }
   // commit: raw pointers from the scratch copy, then retire the superseded set (the stream is idle)
   w->mel_pad = n.mel_pad; w->conv1_out = n.conv1_out; w->x = n.x; w->h = n.h; w->qk = n.qk; w->vt = n.vt; w->att = n.att; w->g = n.g;
-  w->feat = n.feat; w->cross_k = n.cross_k; w->cross_v = n.cross_v; w->self_k = n.self_k; w->self_v = n.self_v; w->dx = n.dx; w->dh = n.dh;
+  w->feat = n.feat; w->enc_part = n.enc_part; w->enc_stat = n.enc_stat; w->cross_k = n.cross_k; w->cross_v = n.cross_v; w->self_k = n.self_k; w->self_v = n.self_v; w->dx = n.dx; w->dh = n.dh;
   w->dq = n.dq; w->da = n.da; w->dg = n.dg; w->partial = n.partial; w->dstat = n.dstat; w->logits = n.logits; w->tokens = n.tokens; w->n_gen = n.n_gen;
   w->finished = n.finished; w->last_ts = n.last_ts; w->out_n = n.out_n; w->sum_logprob = n.sum_logprob; w->n_logprob = n.n_logprob;
   w->no_speech = n.no_speech; w->uniforms = n.uniforms; w->out_tokens = n.out_tokens; w->out_avg = n.out_avg; w->clip = n.clip;
@@ -160,18 +162,26 @@ int whisper_encode_from_padded_mel(mia_whisper* w, int B) {
       if (arc) return mia_fail(w->ctx, MIA_ERR_DEVICE, "attention launch failed");
     }
     {
-      GemmArgs g;
-      g.A = w->att; g.lda = D; g.W = b.out.w; g.bias = b.out.b;
-      g.R = w->x; g.ldr = D; g.C = w->x; g.ldc = D; g.out_f32 = 1;
-      g.M = M; g.N = D; g.K = D;
-      if ((rc = gemm(w, g)) != MIA_OK) return rc;
-    }
-    if ((rc = norm(w, b.mlp_ln, w->h, M, D)) != MIA_OK) return rc;
-    {
-      GemmArgs g;
-      g.A = w->h; g.lda = D; g.W = b.mlp1.w; g.bias = b.mlp1.b; g.act = MIA_ACT_GELU;
-      g.C = w->g; g.ldc = 4 * D; g.M = M; g.N = 4 * D; g.K = D;
-      if ((rc = gemm(w, g)) != MIA_OK) return rc;
+      // out-proj (+ residual) and the MLP's first Linear; when both run on the 8-phase kernel's row epilogues the LayerNorm between them
+      // is carried through the GEMMs (gemm.h) instead of a pass of its own over the fp32 stream
+      GemmArgs go, g1;
+      go.A = w->att; go.lda = D; go.W = b.out.w; go.bias = b.out.b;
+      go.R = w->x; go.ldr = D; go.C = w->x; go.ldc = D; go.out_f32 = 1;
+      go.M = M; go.N = D; go.K = D; go.variant = w->gemm_variant;
+      g1.A = w->h; g1.lda = D; g1.W = b.mlp1.w; g1.bias = b.mlp1.b; g1.act = MIA_ACT_GELU;
+      g1.C = w->g; g1.ldc = 4 * D; g1.M = M; g1.N = 4 * D; g1.K = D; g1.variant = w->gemm_variant;
+      GemmArgs fo = go, f1 = g1;
+      fo.ln_gamma = b.mlp_ln.g; fo.ln_out = w->h; fo.ln_ld = D; fo.ln_part = w->enc_part;
+      f1.ln_stat = w->enc_stat; f1.ln_c1 = b.mlp1.c1; f1.bias = b.mlp1.c2;
+      const bool carry = b.mlp1.c1 && b.mlp1.c2 && mia_gemm_ln_ok(fo) && mia_gemm_ln_ok(f1);
+      if ((rc = gemm(w, carry ? fo : go)) != MIA_OK) return rc;
+      if (carry) {
+        const int rec = mia_prof_begin(w->ctx, MIA_PROF_ENC_NORM, (double)M * (D / 64) * 8.0);
+        const int frc = mia_ln_finalize_launch(w->enc_part, D / 64, D, 1e-5f, w->enc_stat, M, s);
+        mia_prof_end(w->ctx, rec);
+        if (frc) return mia_fail(w->ctx, MIA_ERR_DEVICE, "ln finalize launch failed");
+      } else if ((rc = norm(w, b.mlp_ln, w->h, M, D)) != MIA_OK) return rc;
+      if ((rc = gemm(w, carry ? f1 : g1)) != MIA_OK) return rc;
     }
     {
       GemmArgs g;

@@ -240,7 +240,7 @@ extern "C" mia_whisper* mia_whisper_load(mia_ctx* ctx, const mia_whisper_dims* d
     w->tok_emb_f = frag(w->tok_emb, d.n_vocab, D);
     if (!ok) { mia_whisper_free(w); return fail("fragment-order repack of the decoder weights failed"); }
     // LayerNorm fold constants of every decoder Linear that consumes a LayerNorm (whisper.h LinearW::c1 / c2; decode.h)
-    auto fold = [&](const void* w16, int N, const LNW& ln, float** c1, float** c2) {
+    auto fold = [&](const void* w16, int N, const LNW& ln, float** c1, float** c2, const float* bias = nullptr) {
       if (!ok || !w16) return;
       void* p1 = nullptr; void* p2 = nullptr;
       if (hipMalloc(&p1, (size_t)N * 4) != hipSuccess) { ok = false; return; }
@@ -248,7 +248,7 @@ extern "C" mia_whisper* mia_whisper_load(mia_ctx* ctx, const mia_whisper_dims* d
       if (hipMalloc(&p2, (size_t)N * 4) != hipSuccess) { ok = false; return; }
       w->allocs.push_back(p2);
       *c1 = (float*)p1; *c2 = (float*)p2;
-      if (dec_launch_lnfold(w16, N, D, ln.g, ln.b, *c1, *c2, w->dtype, ctx->stream) != 0) ok = false;
+      if (dec_launch_lnfold(w16, N, D, ln.g, ln.b, *c1, *c2, w->dtype, ctx->stream, bias) != 0) ok = false;
     };
     for (DecBlockW& b : w->dec) {
       fold(b.qkv.w, b.qkv.N, b.attn_ln, &b.qkv.c1, &b.qkv.c2);
@@ -256,6 +256,9 @@ extern "C" mia_whisper* mia_whisper_load(mia_ctx* ctx, const mia_whisper_dims* d
       fold(b.mlp1.w, b.mlp1.N, b.mlp_ln, &b.mlp1.c1, &b.mlp1.c2);
     }
     fold(w->tok_emb, d.n_vocab, w->dec_ln, &w->emb_c1, &w->emb_c2);
+    // encoder: the Linear behind mlp_ln takes its LayerNorm through the GEMM (gemm.h "LayerNorm carried across two GEMMs"); c2 includes the bias
+    if (d.n_audio_state == D)
+      for (EncBlockW& b : w->enc) fold(b.mlp1.w, b.mlp1.N, b.mlp_ln, &b.mlp1.c1, &b.mlp1.c2, b.mlp1.b);
     if (!ok) { mia_whisper_free(w); return fail("LayerNorm fold of the decoder weights failed"); }
   }
   if (hipDeviceSynchronize() != hipSuccess) { mia_whisper_free(w); return fail("device error during upload"); }
