@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r01_bench_turbo_b32.json", "r02_bench_turbo_b32.json"])
+@pytest.mark.parametrize("name", ["r01_bench_turbo_b32.json", "r02_bench_turbo_b32.json", "r03_bench_turbo_b32.json"])
 def test_committed_bench_line_has_every_contract_field(name):
     line = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
     d = json.loads(line)

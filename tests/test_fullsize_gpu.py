@@ -202,8 +202,8 @@ def test_orpheus_3b_shape_two_layers(ctx):
 
 def test_whisper_large_v3_full_depth(ctx):
     """large-v3 at FULL depth (32 encoder + 32 decoder layers, d 1280, 20 heads, V 51 866: the per-GPU model of BASELINE configs[4]),
-    2 clips x 96 tokens, bf16 on the bench's N(0, 0.02^2) checkpoint style: encoder features of both clips against the full-size fp32
-    oracle; the step graph's logits (354 kernel nodes per step: cross-KV layer strides up to layer 31) at all 98 positions against the
+    2 clips x 64 tokens, bf16 on the bench's N(0, 0.02^2) checkpoint style: encoder features of both clips against the full-size fp32
+    oracle; the step graph's logits (291 kernel nodes per step: cross-KV layer strides up to layer 31) at all 66 positions against the
     oracle's teacher-forced logits on the same tokens and features, head decisions replayed exactly (tests/_whisper_trace.py).  With
     N(0, 0.02^2) weights the logits are nearly flat (std ~ 0.03), so the oracle's free run and HIP may split early (round 2 saw a
     split at generated index 2 on an 8-layer cut of this model): a split is legal only where the measured logit errors of the two
@@ -219,7 +219,7 @@ def test_whisper_large_v3_full_depth(ctx):
     weights = S.synthetic_weights(dims, seed=3, style="survey", round_to="bf16")
     model = HW.WhisperModel.load(ctx, dims, weights, m.BF16)
     sup = S.synthetic_suppress_list(model.special)
-    budget = 96
+    budget = 64
     o = HW.DecodingOptions(suppress_ids=sup, blank_ids=[220], max_new_tokens=budget)
     clips = [S.synth_clip(40), S.synth_clip(41)]
     model.trace_logits([0, 1])
