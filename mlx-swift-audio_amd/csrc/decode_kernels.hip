@@ -1724,10 +1724,15 @@ static void skinny_qi_launch_m(const SkinnyArgs& a, const QFrag& q, int mode, hi
   const bool nt4 = (int64_t)tiles * a.S * zb >= 16384 || (a.M > 16 && (int64_t)((tiles + 3) / 4) * a.S * zb >= 192);
   int nw = 1;
   for (int cand : {4, 3, 2}) if (per_split % cand == 0 && (per_split / cand >= 2 || cand == 2)) { nw = cand; break; }
+  // the vocabulary-wide head at <= 16 rows: 4 tiles per ONE-wave workgroup, the whole K range in the wave (no LDS reduction, a quarter
+  // of the workgroups) -- Orpheus-3B, V 156 940: 75.4 us as 9 809 four-wave workgroups, 72.6 as one-wave ones, 67.8 in this form
+  // (4 tiles x 4 waves: 107.6)
+  const bool head41 = mode == SK_OUTF32 && tiles >= 4096 && a.M <= 16;
 #define QI_GO(MODE_, NT_, NW_) hipLaunchKernelGGL((skinny_gemm_qi<T, MODE_, NT_, NW_, M16, NP>), dim3((tiles + NT_ - 1) / NT_, a.S, zb), dim3(64 * NW_), 0, s, a, q)
 #define QI_LAUNCH(MODE_)                                                                                   \
   do {                                                                                                     \
-    if (nt4) { if (per_split % 4 == 0) QI_GO(MODE_, 4, 4); else QI_GO(MODE_, 4, 1); }                       \
+    if (head41) QI_GO(MODE_, 4, 1);                                                                        \
+    else if (nt4) { if (per_split % 4 == 0) QI_GO(MODE_, 4, 4); else QI_GO(MODE_, 4, 1); }                  \
     else if (nw == 4) QI_GO(MODE_, 1, 4); else if (nw == 3) QI_GO(MODE_, 1, 3);                             \
     else if (nw == 2) QI_GO(MODE_, 1, 2); else QI_GO(MODE_, 1, 1);                                          \
   } while (0)

@@ -200,6 +200,34 @@ def test_orpheus_3b_shape_two_layers(ctx):
     model.close()
 
 
+def test_orpheus_3b_vocabulary_head_on_packed_weights(ctx):
+    """The packed-weight step at Orpheus-3B's real width and vocabulary (V 156 940: the head GEMM takes its own launch form, 4 tiles per
+    one-wave workgroup over 9 809 tiles with a ragged last workgroup), one layer deep: logits of three stepped tokens against the 16-bit
+    step on the de-quantised checkpoint (tolerance = the 16-bit copy's weight rounding, tests/test_lm_gpu.py) and against the fp32 oracle."""
+    import dataclasses
+    import mlx_swift_audio_amd as m
+    from mlx_swift_audio_amd import lm as HL
+    from oracle import lm as OLM
+    from test_lm_gpu import _quantized_checkpoint
+    cfg = dataclasses.replace(S.LM_CONFIGS["orpheus-3b"], n_layers=1)
+    packed, dense = _quantized_checkpoint(cfg, seed=4)
+    model = HL.CausalLM.load(ctx, cfg, dense, m.BF16)
+    model.attach_q4(packed)
+    ids = np.random.default_rng(3).integers(0, cfg.vocab, 3).tolist()
+    model.use_q4(False)
+    want = [model.forward([t]).copy() for t in ids]
+    model.use_q4(True)
+    model.reset()
+    ref = OLM.LMOracle(cfg, dense).forward(ids).numpy()
+    for i, t in enumerate(ids):
+        got = model.forward([t])
+        sd = ref[i].std()
+        assert got.shape == (cfg.vocab,) and np.isfinite(got).all()
+        assert np.abs(got - want[i]).max() <= 0.06 * sd, (i, np.abs(got - want[i]).max(), sd)
+        assert np.abs(got - ref[i]).max() <= 0.08 * sd, (i, np.abs(got - ref[i]).max(), sd)
+    model.close()
+
+
 def test_whisper_large_v3_full_depth(ctx):
     """large-v3 at FULL depth (32 encoder + 32 decoder layers, d 1280, 20 heads, V 51 866: the per-GPU model of BASELINE configs[4]),
     2 clips x 64 tokens, bf16 on the bench's N(0, 0.02^2) checkpoint style: encoder features of both clips against the full-size fp32
