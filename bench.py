@@ -589,6 +589,9 @@ def main():
     ap.add_argument("--no-lm", action="store_true", help="skip the LM leg (~1 min of checkpoint generation)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: only the N-rank launcher + the per-pass exchange order, on gloo (tests/test_multi_rank.py)")
     ap.add_argument("--lm-batch", type=int, default=32, help="sentences side by side in the batched part of --lm")
+    ap.add_argument("--weight-sharing", choices=["auto", "off"], default="auto",
+                    help="auto: concurrent replicas load the shared decode weights cacheable (mia_whisper_set_weight_sharing), the serial execution "
+                         "streams them non-temporal; off: non-temporal everywhere (the round-2 behaviour)")
     ap.add_argument("--replicas", type=int, default=3,
                     help="model replicas on separate HIP streams; passes are dealt round-robin so the encoder of one batch overlaps the decoder of another (1 = strictly serial passes)")
     ap.add_argument("--phase-log", action="store_true", help="with --schedule phased: log the wall time of every encoder / decoder phase")
@@ -663,6 +666,8 @@ def main():
             # the first replica uploads the weights; the others are clones: own activations / KV caches / step graph, shared weights
             self.model = HW.WhisperModel.load(self.ctx, dims, weights, dtype) if root is None else root.model.clone(self.ctx)
             self.enc_stream = None
+            if max(1, min(args.replicas, args.steps)) > 1 and args.weight_sharing == "auto":
+                self.model.set_weight_sharing(max(1, min(args.replicas, args.steps)))
             if prio:       # the decode chain outranks the queued tiles of another batch's encoder (include/mia.h, mia_whisper_set_encode_stream)
                 self.enc_stream = torch.cuda.Stream(priority=0)
                 self.model.set_encode_stream(self.enc_stream.cuda_stream)
@@ -813,6 +818,17 @@ def main():
     n_serial = 1 if R == 1 else 2
     serial_exec = None
     if R > 1:
+        # a lone decode loop streams its weights non-temporal, concurrent loops on one weight copy load them cacheable
+        # (mia_whisper_set_weight_sharing): the serial execution runs in the lone-loop form -- one untimed pass re-captures the step graph
+        if args.weight_sharing == "auto":
+            reps[0].model.set_weight_sharing(1)
+        base = pass_counter[0]
+        pass_counter[0] += 1
+        reps[0].step(base)
+        if exch is not None:
+            exch.wait_issued(base)
+            xstream.synchronize()
+        fence()
         ctx.profile(True)
         ctx.profile_reset()
         fence()
@@ -830,6 +846,9 @@ def main():
         prof_serial = {k: ctx.profile_read(k) for k in prof_keys}
         serial_exec = {"replicas": 1, "passes": n_serial, "ms_per_step": round(serial_s / n_serial * 1e3, 3), "value": round(30.0 * B * n_serial / serial_s, 2), "unit": "audio-sec/s"}
         ctx.profile(False)
+        if args.weight_sharing == "auto":
+            reps[0].model.set_weight_sharing(R)
+        run_passes(R)                                  # untimed: replica 0 re-captures its step graph in the shared-weights form
     else:
         ctx.profile(True)
         ctx.profile_reset()
@@ -920,6 +939,7 @@ def main():
                                 ("rounds of up to R passes: all encoders, then all decoders concurrently (decoders of different batches overlap each other; an encoder beside a decoder does not)"
                                  if args.schedule == "phased" else
                                  "passes dealt round-robin: the encoder of one batch overlaps the decoder of another") +
+                                "; the decode steps load the shared weights cacheable (mia_whisper_set_weight_sharing; the serial `execution` runs the lone-loop, non-temporal form)" +
                                 "; every pass is a complete log-mel + encode + decode of its 32 clips")},
         "roofline": roofline, "stages": stage,
     }

@@ -277,6 +277,11 @@ int mia_whisper_encode_windows(mia_whisper* w, const float* pcm, const int64_t* 
  * kernels of one batch are then dispatched ahead of the queued tiles of another batch's encoder instead of taking turns with them.
  * NULL restores the single-stream form.  The stream must belong to the context's device and outlive the handle's use of it. */
 int mia_whisper_set_encode_stream(mia_whisper* w, void* hip_stream);
+/* Throughput hint for handles that share one weight copy (mia_whisper_clone) and decode CONCURRENTLY on their own streams: with
+ * concurrent_readers > 1 the decode step loads its weights with the default cache policy (the loops that read a matrix second and third
+ * mostly hit the 256 MB Infinity Cache); with 1 (the default) it streams them non-temporal, which is faster for a lone loop.  Results
+ * are bit-identical either way.  Call on every handle of the group; takes effect at the next decode. */
+int mia_whisper_set_weight_sharing(mia_whisper* w, int concurrent_readers);
 int mia_whisper_transcribe_windows(mia_whisper* w, const float* pcm, const int64_t* offs, int B, int64_t pad_right,
                                    const mia_decode_opts* opts, int32_t* tokens, int32_t* n_tokens, float* avg_logprob,
                                    float* no_speech_prob, int mem);

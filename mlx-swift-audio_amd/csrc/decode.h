@@ -28,6 +28,8 @@ struct SkinnyArgs {
   int M, N, K, S, act, D, H, n_ctx;
   int out_frag = 0;                      // fragment-order kernels, OUT16: write `out` in activation fragment order (row length N)
   int w_frag = 0;                        // row-major-activation kernels (the LM step): W is in weight fragment order
+  int w_keep = 0;                        // fragment-order kernels (the Whisper step): load W with the default cache policy instead of
+                                         // non-temporal -- several decode loops read one weight copy concurrently (mia_whisper_set_weight_sharing)
   // ---- RMSNorm carried across the GEMM chain of the LM step (no separate reduce + norm launch):
   // SK_RESID (needs S == 1): xres[m][n] += acc (+ bias) in place (the fp32 residual stream, row stride N); out[m][n] (16-bit, row stride
   //   ldo) = (x_new * nw[n]) rounded -- the NEXT block's activation, not yet divided by its rms; ss_out[tile][m] = sum of x_new^2 over the

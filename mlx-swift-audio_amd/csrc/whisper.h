@@ -112,6 +112,7 @@ struct mia_whisper {
   void* da = nullptr;                 // 16-bit [B][D]  attention output
   void* dg = nullptr;                 // 16-bit [B][4D]
   float* partial = nullptr;           // fp32 [S_max][B][D] split-K partials
+  int weight_sharing = 0;             // mia_whisper_set_weight_sharing: other handles stream the same weights concurrently
   float* enc_part = nullptr;          // encoder LayerNorm hand-over (gemm.h): [B T][D / 64][2] partial sums, and
   float* enc_stat = nullptr;          // [B T][2] (mean, rstd)
   float* dstat = nullptr;             // fp32 [2][D / 16][B][2]: per-tile (sum x, sum x^2) of the residual rows, written by the SK_RESID projections

@@ -174,6 +174,14 @@ class WhisperModel:
         lib.mia_whisper_set_debug.argtypes = [C.c_void_p, C.c_int]
         self.ctx.check(lib.mia_whisper_set_debug(self.h, int(flags)))
 
+    def set_weight_sharing(self, concurrent_readers: int) -> None:
+        """mia_whisper_set_weight_sharing: > 1 when clones of these weights decode concurrently on other streams (the step then loads
+        its weights cacheable); 1 restores the lone-loop (non-temporal) form.  Results are bit-identical."""
+        lib = self.ctx.lib
+        lib.mia_whisper_set_weight_sharing.restype = C.c_int
+        lib.mia_whisper_set_weight_sharing.argtypes = [C.c_void_p, C.c_int]
+        self.ctx.check(lib.mia_whisper_set_weight_sharing(self.h, int(concurrent_readers)))
+
     def set_encode_stream(self, hip_stream: int | None) -> None:
         """mia_whisper_set_encode_stream: run the encoder half of every window on another HIP stream (raw pointer, e.g.
         torch.cuda.Stream(...).cuda_stream); None restores the single-stream form."""

@@ -86,6 +86,31 @@ def test_encoder_layernorm_handover_on_offset_rows(ctx, dtype_name):
     assert errs[(2.0, 3)][1] <= 1.6 * errs[(2.0, 2)][1], errs                   # moderate offset: bounded loss (measured 1.3x)
 
 
+def test_weight_sharing_hint_changes_no_bits(ctx):
+    """mia_whisper_set_weight_sharing only switches the cache policy of the step's weight loads (and re-captures the step graph): tokens,
+    log-probs and traced logits are bit-identical with the hint on and off."""
+    dims, oracle, model = _models(ctx, "micro", "bf16", seed=5)
+    from mlx_swift_audio_amd import whisper as HW
+    st = OW.SpecialTokens.for_vocab(dims.n_vocab)
+    o = HW.DecodingOptions(suppress_ids=OW.synthetic_suppress_list(st), blank_ids=[220], max_new_tokens=24)
+    mel = _mel(dims, 3, 1, "bf16")
+    runs = []
+    for readers in (1, 3, 1):
+        model.set_weight_sharing(readers)
+        model.trace_logits([0, 2])
+        model.encode(mel)
+        res = model.decode_greedy(o)
+        n_pos = min(len(r.tokens) for r in res)
+        runs.append(([r.tokens for r in res], [np.float32(r.avg_logprob) for r in res], [model.read_logit_trace(s, 0, n_pos).copy() for s in range(2)]))
+    for other in runs[1:]:
+        assert other[0] == runs[0][0]
+        assert np.array_equal(np.asarray(other[1]), np.asarray(runs[0][1]), equal_nan=True)
+        for a, b in zip(other[2], runs[0][2]):
+            np.testing.assert_array_equal(a, b)
+    model.trace_logits([])
+    model.close()
+
+
 @pytest.mark.parametrize("variant", [0, 2, 4])
 def test_encoder_forced_tile_variants(ctx, variant):
     """The 256^2 tiles (and their operand-swapped V path) are only auto-selected at full size: force them on the reduced model."""
