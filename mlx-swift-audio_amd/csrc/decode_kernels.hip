@@ -749,6 +749,11 @@ struct WFragBuf {
     const unsigned bytes = (unsigned)(((a.N + 15) >> 4) << 4) * (unsigned)a.K * 2u;          // wave-uniform
     rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), (short)0, (int)bytes, 0x00020000);
   }
+  // the activation fragments of the same GEMM ([ceil(M / 32)][K / 32][2][64 lanes][8])
+  __device__ __forceinline__ WFragBuf(const SkinnyArgs& a, int) : base(a.A) {
+    const unsigned bytes = (unsigned)(((a.M + 31) >> 5) << 5) * (unsigned)a.K * 2u;
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.A), (short)0, (int)bytes, 0x00020000);
+  }
   __device__ __forceinline__ uint32_t offset(const uint16_t* p) const { return (uint32_t)((const char*)p - (const char*)base); }
   template <int AUX>
   __device__ __forceinline__ s16x8 load(uint32_t byte_off) const {
@@ -781,6 +786,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fflat(SkinnyArgs a) {
   //  forms then ran cacheable.  The policy is therefore the immediate `aux` operand of a buffer load, which cannot be merged: 0 = default,
   //  2 = nt.)
   const WFragBuf wb(a);
+  const WFragBuf ab(a, 0);
+  const uint32_t ao = ab.offset(ap);
   uint32_t wo[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wo[t] = wb.offset(wp[t]);
@@ -790,8 +797,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fflat(SkinnyArgs a) {
     for (int u = 0; u < NSTEP; ++u) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) fw[u][n] = wb.template load<AUX>(wo[n] + 1024u * u);
-      fa0[u] = *reinterpret_cast<const s16x8*>(ap + 1024 * u);
-      fa1[u] = *reinterpret_cast<const s16x8*>(ap + 1024 * u + 512);
+      fa0[u] = ab.template load<0>(ao + 2048u * u);
+      fa1[u] = ab.template load<0>(ao + 2048u * u + 1024u);
     }
   };
   if (a.w_keep) load_all(std::true_type{}); else load_all(std::false_type{});
@@ -837,6 +844,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
   struct Batch { s16x8 w[KB][NT], a0[KB], a1[KB]; };
   const bool keep = a.w_keep != 0;      // cache policy of the weight loads (see dec_skinny_fflat); wave-uniform, one test per batch
   const WFragBuf wb(a);
+  const WFragBuf ab(a, 0);
+  const uint32_t ao = ab.offset(ap);
   uint32_t wo[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wo[t] = wb.offset(wp[t]);
@@ -847,8 +856,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_fring(SkinnyArgs a) {
       for (int u = 0; u < KB; ++u) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) t.w[u][n] = wb.template load<AUX>(wo[n] + 1024u * (uint32_t)(ks + u));
-        t.a0[u] = *reinterpret_cast<const s16x8*>(ap + 1024 * (ks + u));
-        t.a1[u] = *reinterpret_cast<const s16x8*>(ap + 1024 * (ks + u) + 512);
+        t.a0[u] = ab.template load<0>(ao + 2048u * (uint32_t)(ks + u));
+        t.a1[u] = ab.template load<0>(ao + 2048u * (uint32_t)(ks + u) + 1024u);
       }
     };
     if (keep) go(std::true_type{}); else go(std::false_type{});
@@ -1112,15 +1121,15 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = T::to_f32((uint16_t)qv[j]);
   }
-  auto ld = [](const uint16_t* p) -> s16x8 {
-    if (NTL) return __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(p));
-    return *reinterpret_cast<const s16x8*>(p);
-  };
-  auto load_trip = [&](s16x8 (&dst)[U], const uint16_t* base, int k0) {
+  // K / V of this (clip, head) as buffer resources: 16-byte loads at 32-bit offsets (no 64-bit address arithmetic per load), the cache
+  // policy in the instruction's aux immediate (2 = non-temporal)
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kb), (short)0, cap_keys * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vb), (short)0, cap_keys * 128, 0x00020000);
+  auto load_trip = [&](s16x8 (&dst)[U], const __amdgpu_buffer_rsrc_t& base, int k0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int key = k0 + 8 * u + g; key = key < nk ? key : nk - 1;
-      dst[u] = ld(base + (int64_t)key * 64 + c * 8);
+      dst[u] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(base, key * 128 + c * 16, 0, NTL ? 2 : 0));
     }
   };
   constexpr int TRIP = 32 * U;   // keys per workgroup trip; a wave owns 8 U consecutive keys of it
@@ -1128,10 +1137,10 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   {
     int k0 = wave * (8 * U);
     s16x8 kv[U], kn[U];
-    if (k0 < nk) load_trip(kv, kb, k0);
+    if (k0 < nk) load_trip(kv, rk, k0);
     for (; k0 < nk; k0 += TRIP) {
       const bool more = k0 + TRIP < nk;
-      if (more) load_trip(kn, kb, k0 + TRIP);
+      if (more) load_trip(kn, rk, k0 + TRIP);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float dot = 0.f;
@@ -1151,7 +1160,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   }
   // the first V trip does not depend on the probabilities: its loads fly during the softmax
   s16x8 vv[U], vn[U];
-  if (wave * (8 * U) < nk) load_trip(vv, vb, wave * (8 * U));
+  if (wave * (8 * U) < nk) load_trip(vv, rv, wave * (8 * U));
   __syncthreads();
   // word-timestamp alignment (WhisperTiming.swift:605-640): keep the pre-softmax scores of the alignment heads, row = decoder position
   if (qk_out && head_slot[h] >= 0) {
@@ -1177,7 +1186,7 @@ __global__ __launch_bounds__(256) void dec_attention(const uint16_t* __restrict_
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   for (int k0 = wave * (8 * U); k0 < nk; k0 += TRIP) {
     const bool more = k0 + TRIP < nk;
-    if (more) load_trip(vn, vb, k0 + TRIP);
+    if (more) load_trip(vn, rv, k0 + TRIP);
     float pw[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
