@@ -397,6 +397,33 @@ __device__ __forceinline__ void skinny_store(const SkinnyArgs& a, f32x4 (&acc)[N
   }
 }
 
+// The fragment-order weight matrix of a Whisper-step GEMM as a buffer resource: 16-byte loads at 32-bit byte offsets whose cache policy
+// is the instruction's immediate `aux` operand (0 = default, 2 = non-temporal).
+struct WFragBuf {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t rs;
+  const uint16_t* base;
+  __device__ __forceinline__ explicit WFragBuf(const SkinnyArgs& a) : base(a.W) {
+    const unsigned bytes = (unsigned)(((a.N + 15) >> 4) << 4) * (unsigned)a.K * 2u;          // wave-uniform
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), (short)0, (int)bytes, 0x00020000);
+  }
+  // the activation fragments of the same GEMM ([ceil(M / 32)][K / 32][2][64 lanes][8])
+  __device__ __forceinline__ WFragBuf(const SkinnyArgs& a, int) : base(a.A) {
+    const unsigned bytes = (unsigned)(((a.M + 31) >> 5) << 5) * (unsigned)a.K * 2u;
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.A), (short)0, (int)bytes, 0x00020000);
+  }
+  // the LM step's weight matrix: row-major [N][K] or fragment order (rows padded to 16)
+  __device__ __forceinline__ WFragBuf(const SkinnyArgs& a, bool frag) : base(a.W) {
+    const unsigned rows = frag ? (unsigned)(((a.N + 15) >> 4) << 4) : (unsigned)a.N;
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), (short)0, (int)(rows * (unsigned)a.K * 2u), 0x00020000);
+  }
+  __device__ __forceinline__ uint32_t offset(const uint16_t* p) const { return (uint32_t)((const char*)p - (const char*)base); }
+  template <int AUX>
+  __device__ __forceinline__ s16x8 load(uint32_t byte_off) const {
+    return __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, AUX));
+  }
+};
+
 template <typename T, int MODE, int NT, int KB, int NW>
 __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
   __shared__ float rs[32];
@@ -422,6 +449,12 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
       wp[t] = a.W + (int64_t)wn * a.K + kbeg + 8 * c;
     }
   }
+  // weight loads as buffer loads at 32-bit byte offsets (no 64-bit address arithmetic per load; see dec_skinny_fflat)
+  const WFragBuf wbuf(a, a.w_frag != 0);
+  uint32_t wo[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wo[t] = wbuf.offset(wp[t]);
+  const uint32_t wsb = (uint32_t)ws * 2u;
   int am0 = m0 + r; am0 = am0 < a.M ? am0 : a.M - 1;
   int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
   const uint16_t* ap0 = a.A + (int64_t)am0 * a.lda + kbeg + 8 * c;
@@ -444,7 +477,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) t.w[u][n] = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)((k >> 5) + u) * ws);
+      for (int n = 0; n < NT; ++n) t.w[u][n] = wbuf.template load<0>(wo[n] + (uint32_t)((k >> 5) + u) * wsb);
       t.a0[u] = lda0(ap0 + k + 32 * u);
       t.a1[u] = lda1(ap1 + k + 32 * u);
     }
@@ -473,7 +506,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
     for (int u = 0; u < KB; ++u)
       if (u < rem) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b3.w[u][n] = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)((ktail >> 5) + u) * ws);
+        for (int n = 0; n < NT; ++n) b3.w[u][n] = wbuf.template load<0>(wo[n] + (uint32_t)((ktail >> 5) + u) * wsb);
         b3.a0[u] = lda0(ap0 + ktail + 32 * u);
         b3.a1[u] = lda1(ap1 + ktail + 32 * u);
       }
@@ -515,7 +548,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
       const s16x8 fa1 = lda1(ap1 + k);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const s16x8 fw = *reinterpret_cast<const s16x8*>(wp[n] + (int64_t)(k >> 5) * ws);
+        const s16x8 fw = wbuf.template load<0>(wo[n] + (uint32_t)(k >> 5) * wsb);
         acc[n][0] = T::mfma16(fw, fa0, acc[n][0]);
         acc[n][1] = T::mfma16(fw, fa1, acc[n][1]);
       }
@@ -553,6 +586,11 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
       wp[t] = a.W + (int64_t)wn * a.K + kbeg + 8 * c;
     }
   }
+  const WFragBuf wbuf(a, a.w_frag != 0);
+  uint32_t wo[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wo[t] = wbuf.offset(wp[t]);
+  const uint32_t wsb = (uint32_t)ws * 2u;
   int am0 = m0 + r; am0 = am0 < a.M ? am0 : a.M - 1;
   int am1 = m0 + 16 + r; am1 = am1 < a.M ? am1 : a.M - 1;
   const uint16_t* ap0 = a.A + (int64_t)am0 * a.lda + kbeg + 8 * c;
@@ -563,7 +601,7 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_flat(SkinnyArgs a) {
 #pragma unroll
   for (int u = 0; u < NSTEP; ++u) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) fw[u][n] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp[n] + (int64_t)u * ws));
+    for (int n = 0; n < NT; ++n) fw[u][n] = wbuf.template load<2>(wo[n] + (uint32_t)u * wsb);
     fa0[u] = zfrag; fa1[u] = zfrag;
     if (av0) fa0[u] = *reinterpret_cast<const s16x8*>(ap0 + 32 * u);
     if (av1) fa1[u] = *reinterpret_cast<const s16x8*>(ap1 + 32 * u);
@@ -738,28 +776,6 @@ __device__ __forceinline__ void skinny_resid_frag(const SkinnyArgs& a, const f32
     }
   }
 }
-
-// The fragment-order weight matrix of a Whisper-step GEMM as a buffer resource: 16-byte loads at 32-bit byte offsets whose cache policy
-// is the instruction's immediate `aux` operand (0 = default, 2 = non-temporal).
-struct WFragBuf {
-  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-  __amdgpu_buffer_rsrc_t rs;
-  const uint16_t* base;
-  __device__ __forceinline__ explicit WFragBuf(const SkinnyArgs& a) : base(a.W) {
-    const unsigned bytes = (unsigned)(((a.N + 15) >> 4) << 4) * (unsigned)a.K * 2u;          // wave-uniform
-    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), (short)0, (int)bytes, 0x00020000);
-  }
-  // the activation fragments of the same GEMM ([ceil(M / 32)][K / 32][2][64 lanes][8])
-  __device__ __forceinline__ WFragBuf(const SkinnyArgs& a, int) : base(a.A) {
-    const unsigned bytes = (unsigned)(((a.M + 31) >> 5) << 5) * (unsigned)a.K * 2u;
-    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.A), (short)0, (int)bytes, 0x00020000);
-  }
-  __device__ __forceinline__ uint32_t offset(const uint16_t* p) const { return (uint32_t)((const char*)p - (const char*)base); }
-  template <int AUX>
-  __device__ __forceinline__ s16x8 load(uint32_t byte_off) const {
-    return __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, AUX));
-  }
-};
 
 template <typename T, int MODE, int NT, int NSTEP, int NW>
 __global__ __launch_bounds__(64 * NW) void dec_skinny_fflat(SkinnyArgs a) {
@@ -1016,6 +1032,15 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_qi(SkinnyArgs a, QFrag q)
     wp[t] = reinterpret_cast<const u32x4*>(q.wfrag) + ((int64_t)tl * nblk) * (NP * 64) + lane;
     sp[t] = reinterpret_cast<const f32x4*>(q.stfrag) + ((int64_t)tl * nblk) * 16 + r;      // (s, t) of the block's two groups for column r
   }
+  // codes and (scale, offset) pairs as buffer loads at 32-bit byte offsets, non-temporal (aux 2): see dec_skinny_fflat
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(q.wfrag), (short)0, (int)((unsigned)n_tiles * (unsigned)nblk * (NP * 64 * 16u)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.stfrag), (short)0, (int)((unsigned)n_tiles * (unsigned)nblk * 256u), 0x00020000);
+  uint32_t wo[NT], so[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    wo[t] = (uint32_t)((const char*)wp[t] - (const char*)q.wfrag);
+    so[t] = (uint32_t)((const char*)sp[t] - (const char*)q.stfrag);
+  }
   f32x4 acc[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -1025,8 +1050,8 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_qi(SkinnyArgs a, QFrag q)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) b.w[t][p] = __builtin_nontemporal_load(wp[t] + ((int64_t)blk * NP + p) * 64);
-      b.st[t] = __builtin_nontemporal_load(sp[t] + (int64_t)blk * 16);
+      for (int p = 0; p < NP; ++p) b.w[t][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(wo[t] + (uint32_t)(blk * NP + p) * 1024u), 0, 2));
+      b.st[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rst, (int)(so[t] + (uint32_t)blk * 256u), 0, 2));
     }
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
