@@ -417,6 +417,11 @@ struct WFragBuf {
     const unsigned rows = frag ? (unsigned)(((a.N + 15) >> 4) << 4) : (unsigned)a.N;
     rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.W), (short)0, (int)(rows * (unsigned)a.K * 2u), 0x00020000);
   }
+  // the LM step's row-major activations [M][lda]
+  struct RowMajorA {};
+  __device__ __forceinline__ WFragBuf(const SkinnyArgs& a, RowMajorA) : base(a.A) {
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.A), (short)0, (int)((unsigned)a.M * (unsigned)a.lda * 2u), 0x00020000);
+  }
   __device__ __forceinline__ uint32_t offset(const uint16_t* p) const { return (uint32_t)((const char*)p - (const char*)base); }
   template <int AUX>
   __device__ __forceinline__ s16x8 load(uint32_t byte_off) const {
@@ -465,8 +470,10 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
   // instructions of every K-step.
   const bool av0 = m0 + r < a.M, av1 = m0 + 16 + r < a.M;
   const s16x8 zfrag = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
-  auto lda0 = [&](const uint16_t* p) -> s16x8 { s16x8 v = zfrag; if (av0) v = *reinterpret_cast<const s16x8*>(p); return v; };
-  auto lda1 = [&](const uint16_t* p) -> s16x8 { s16x8 v = zfrag; if (av1) v = *reinterpret_cast<const s16x8*>(p); return v; };
+  const WFragBuf abuf(a, WFragBuf::RowMajorA{});
+  const uint32_t ab0 = abuf.offset(ap0), ab1 = abuf.offset(ap1);
+  auto lda0 = [&](int k) -> s16x8 { s16x8 v = zfrag; if (av0) v = abuf.template load<0>(ab0 + 2u * (uint32_t)k); return v; };
+  auto lda1 = [&](int k) -> s16x8 { s16x8 v = zfrag; if (av1) v = abuf.template load<0>(ab1 + 2u * (uint32_t)k); return v; };
   f32x4 acc[NT][2];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -478,8 +485,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
     for (int u = 0; u < KB; ++u) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) t.w[u][n] = wbuf.template load<0>(wo[n] + (uint32_t)((k >> 5) + u) * wsb);
-      t.a0[u] = lda0(ap0 + k + 32 * u);
-      t.a1[u] = lda1(ap1 + k + 32 * u);
+      t.a0[u] = lda0(k + 32 * u);
+      t.a1[u] = lda1(k + 32 * u);
     }
   };
   auto mma_batch = [&](const Batch& t) {
@@ -507,8 +514,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
       if (u < rem) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) b3.w[u][n] = wbuf.template load<0>(wo[n] + (uint32_t)((ktail >> 5) + u) * wsb);
-        b3.a0[u] = lda0(ap0 + ktail + 32 * u);
-        b3.a1[u] = lda1(ap1 + ktail + 32 * u);
+        b3.a0[u] = lda0(ktail + 32 * u);
+        b3.a1[u] = lda1(ktail + 32 * u);
       }
   }
   if (nb > 0) {
@@ -544,8 +551,8 @@ __global__ __launch_bounds__(64 * NW) void dec_skinny_gemm(SkinnyArgs a) {
       }
   } else {
     for (int k = ktail; k < Kc; k += 32) {
-      const s16x8 fa0 = lda0(ap0 + k);
-      const s16x8 fa1 = lda1(ap1 + k);
+      const s16x8 fa0 = lda0(k);
+      const s16x8 fa1 = lda1(k);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const s16x8 fw = wbuf.template load<0>(wo[n] + (uint32_t)(k >> 5) * wsb);
